@@ -1,0 +1,140 @@
+/* spam_hip.h — C ABI of libspam_hip.so: the MI355X (gfx950) back end for the spam_csr hot path.
+ *
+ * What this replaces.  The reference (sledgehammervampire/sparse_matrix, Rust) has no FFI or plug-in
+ * interface; its one product is `CsrMatrix::mul_hash::<B1, B2>` (spam_csr/src/mul_hash.rs:13-36),
+ * reached through `impl Mul for &CsrMatrix` (spam_csr/src/lib.rs:292-297) and through the method-name
+ * macros `gen_bench_mul!($f)` / `gen_mul_main!($f)` (spam_csr/src/lib.rs:386-467).  A backend therefore
+ * lives in a new module next to `mod mul_hash;` (lib.rs:21) and binds the entry points below from an
+ * `extern "C"` block (INTEGRATION.md shows the Rust shim).  Every entry point cites the reference code
+ * it stands in for.  Plain pointers and sizes only; all HIP runtime use is inside the library.
+ *
+ * Host layout == the reference's: `offsets: Vec<usize>`, `indices: Vec<usize>`, `vals: Vec<T>`
+ * (spam_csr/src/lib.rs:25-32), usize == uint64_t.  Device layout: uint64 row_ptr, uint32 col_idx
+ * (the reference already truncates column keys to u32, mul_hash.rs:12,92,157), T vals.
+ *
+ * Errors: the reference panics (checked_add unwrap mul_hash.rs:47-48 / lib.rs:270; slice OOB on an
+ * inner-dimension mismatch mul_hash.rs:46; assert_eq! mul_hash.rs:190).  Here every function returns a
+ * status and records a message for spam_last_error(); the Rust shim turns non-zero into panic!().
+ * Unlike the reference, A.cols == B.rows is checked up front.
+ *
+ * Threading: handles may be read concurrently; calls that create or free a handle, and the global
+ * device/stream selection, must not race.  One process drives one GPU (one rank per GPU under RCCL).
+ */
+#ifndef SPAM_HIP_H
+#define SPAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPAM_OK 0
+#define SPAM_E_INVALID 1     /* null/ill-formed argument, dimension mismatch (ref: OOB panic, mul_hash.rs:46) */
+#define SPAM_E_INDEX_RANGE 2 /* cols >= 2^32-1: column keys must fit u32 and != u32::MAX (mul_hash.rs:12, set.rs:110) */
+#define SPAM_E_OOM 3         /* device or host allocation failed */
+#define SPAM_E_HIP 4         /* HIP runtime error (message has the hipError string) */
+#define SPAM_E_OVERFLOW 5    /* checked_add overflow (mul_hash.rs:47-48, lib.rs:270) */
+#define SPAM_E_UNSUPPORTED 6 /* valid request this build cannot serve (message says why) */
+#define SPAM_E_DTYPE 7       /* f32 entry point called on an f64 handle or vice versa */
+
+#define SPAM_F32 0
+#define SPAM_F64 1
+
+typedef struct spam_csr spam_csr;                 /* device-resident CsrMatrix<T, IS_SORTED> */
+typedef struct spam_spgemm_plan spam_spgemm_plan; /* state between symbolic and numeric (mul_hash.rs:22,28) */
+
+/* Measured facts about one SpGEMM call; all counts exact. */
+typedef struct spam_spgemm_stats {
+  uint64_t rows, inner, cols;      /* C is rows x cols, inner = A.cols = B.rows */
+  uint64_t nnz_a, nnz_b, nnz_c;
+  uint64_t flops_f;                /* F = sum of intermediate products (row_nz before symbolic, mul_hash.rs:39-50) */
+  uint64_t rows_sym_bin[8];        /* rows per symbolic bin (by F)   */
+  uint64_t rows_num_bin[8];        /* rows per numeric bin (by nnz)  */
+  uint64_t heavy_items;            /* (row, column-chunk) work items on the dense-chunk path */
+  float ms_flops, ms_symbolic, ms_alloc, ms_numeric, ms_total; /* device time, HIP events on the library stream */
+} spam_spgemm_stats;
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+
+/* Select the GPU this process drives (hipSetDevice) and check it is gfx950.  device = LOCAL_RANK. */
+int spam_hip_init(int device);
+/* Use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) for all launches; NULL = default stream. */
+int spam_hip_set_stream(void* hip_stream);
+/* Block until everything queued on the library stream has finished. */
+int spam_hip_synchronize(void);
+/* Message of the last failing call on this thread ("" if none).  Never NULL. */
+const char* spam_last_error(void);
+/* Library/ABI version: major*1000 + minor. */
+int spam_version(void);
+
+/* ---- CsrMatrix <-> device ------------------------------------------------------------------ */
+
+/* Upload a host CsrMatrix (struct fields, spam_csr/src/lib.rs:25-32).  Narrows indices to u32 on the
+ * device; fails with SPAM_E_INDEX_RANGE if cols >= 2^32-1, SPAM_E_INVALID if the arrays break
+ * invariants 2,3,4,5,7 (lib.rs:51-67,79-81).  is_sorted = the const generic IS_SORTED. */
+int spam_csr_upload_f64(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t* offsets,
+                        const uint64_t* indices, const double* vals, int is_sorted, spam_csr** out);
+int spam_csr_upload_f32(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t* offsets,
+                        const uint64_t* indices, const float* vals, int is_sorted, spam_csr** out);
+
+/* Wrap arrays already in HBM (no copy, caller keeps ownership and must outlive the handle):
+ * d_row_ptr uint64[rows+1], d_col_idx uint32[nnz], d_vals T[nnz]; all 16-byte aligned. */
+int spam_csr_from_device(int dtype, uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t* d_row_ptr,
+                         const uint32_t* d_col_idx, const void* d_vals, int is_sorted, spam_csr** out);
+
+/* A view of rows [row_lo, row_hi) of `a` as its own matrix (shares col_idx/vals with `a`, which must
+ * outlive it).  Used to hand each GPU its row block of A (rows_to_threads with tnum = #GPUs). */
+int spam_csr_row_block(const spam_csr* a, uint64_t row_lo, uint64_t row_hi, spam_csr** out);
+
+int spam_csr_dims(const spam_csr* m, uint64_t* rows, uint64_t* cols, uint64_t* nnz, int* dtype, int* is_sorted);
+/* Raw device pointers (for RCCL all-gather of B's arrays by the caller, or zero-copy torch views). */
+int spam_csr_device_ptrs(const spam_csr* m, const uint64_t** d_row_ptr, const uint32_t** d_col_idx,
+                         const void** d_vals);
+/* Copy back into caller-allocated host Vecs (offsets[rows+1], indices[nnz] widened to usize, vals[nnz]). */
+int spam_csr_download_f64(const spam_csr* m, uint64_t* offsets, uint64_t* indices, double* vals);
+int spam_csr_download_f32(const spam_csr* m, uint64_t* offsets, uint64_t* indices, float* vals);
+/* CsrMatrix::invariants() 1-7 evaluated on the device (spam_csr/src/lib.rs:47-81,152-160).  *ok = 0/1. */
+int spam_csr_invariants(const spam_csr* m, int* ok);
+void spam_csr_free(spam_csr* m);
+
+/* ---- SpMV: y = A x --------------------------------------------------------------------------
+ * Absent from the reference; defined as mul_hash with an n x 1 right-hand side (SURVEY.md §3.5,
+ * mul_hash.rs:145-163): rows without entries give 0.  x has cols(A) entries, y rows(A). */
+int spam_spmv_f64(const spam_csr* a, const double* x_host, double* y_host); /* host slices (&[T] -> Vec<T>) */
+int spam_spmv_f32(const spam_csr* a, const float* x_host, float* y_host);
+int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y); /* device-resident vectors, asynchronous */
+
+/* ---- SpGEMM: C = A B, two phases like mul_hash ----------------------------------------------
+ * spam_spgemm_symbolic  = rows_to_threads' flop count (mul_hash.rs:39-50) + mul_hash_symbolic (:66-103)
+ *                         + checked_inclusive_scan (lib.rs:267-274); *nnz_out = nnz(C), so the caller can
+ *                         Vec::with_capacity(nnz) exactly as mul_hash.rs:119 does.
+ * spam_spgemm_numeric_* = mul_hash_numeric::<B1, B2> (:106-201); sort_rows is the const generic B2
+ *                         (rows sorted by column).  With sort_rows = 0 each row is emitted in this
+ *                         library's own table order: the same SET of (col, value) per row as the
+ *                         reference, not its linprobe slot order.  Explicit zeros are kept (structure =
+ *                         symbolic pattern), as in the reference. */
+int spam_spgemm_symbolic(const spam_csr* a, const spam_csr* b, spam_spgemm_plan** plan, uint64_t* nnz_out);
+int spam_spgemm_numeric_f64(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out /* rows+1 */,
+                            uint64_t* indices_out /* nnz */, double* vals_out /* nnz */);
+int spam_spgemm_numeric_f32(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out, uint64_t* indices_out,
+                            float* vals_out);
+/* Same, but C stays in HBM as a new handle (free with spam_csr_free). */
+int spam_spgemm_numeric_dev(spam_spgemm_plan* plan, int sort_rows, spam_csr** c_out);
+int spam_spgemm_plan_stats(const spam_spgemm_plan* plan, spam_spgemm_stats* stats);
+void spam_spgemm_plan_free(spam_spgemm_plan* plan);
+
+/* One call, device-resident: symbolic + allocate + numeric.  stats may be NULL. */
+int spam_spgemm_dev(const spam_csr* a, const spam_csr* b, int sort_rows, spam_csr** c_out,
+                    spam_spgemm_stats* stats);
+
+/* rows_to_threads (mul_hash.rs:38-64) with tnum = nparts: per-row intermediate-product counts and the
+ * flop-balanced contiguous row ranges rows_offset[0..nparts].  row_flops_out may be NULL. */
+int spam_rows_to_parts(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t* row_flops_out /* rows */,
+                       uint64_t* rows_offset_out /* nparts+1 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPAM_HIP_H */

@@ -1,0 +1,424 @@
+// spam_oracle.cpp — CPU restatement of the reference's spam_csr hot path.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load liboracle.so; the product (libspam_hip.so) never links or calls it.
+//
+// The reference (sledgehammervampire/sparse_matrix) is Rust; no Rust toolchain exists in the build
+// image, so the reference itself cannot be compiled.  This file follows the Rust
+// sources line by line; every function cites the reference file:line it restates.
+//
+// Parity status: the reference holds NO golden vectors / fixtures for this path.  The restatement is
+// pinned by (a) the reference's own property tests P1-P4 restated in tests/ (spam_csr/src/tests.rs:
+// 356-371, mul_hash.rs:204-224, fuzz/fuzz_targets/mul_hash.rs:28-46, lib.rs:47-81), and (b) slot-order
+// known answers derived by hand from linprobe's code (tests/golden/linprobe_kat.json).
+// SpMV does not exist in the reference: "parity unpinned" upstream; here it is DEFINED as mul_hash with
+// an n x 1 right-hand side and orc_spmv_* is checked against exactly that.
+//
+// Build: g++ -O2 -ffp-contract=off -shared -fPIC (Rust never contracts a*b + c into an FMA; neither
+// may this file).
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+namespace {
+
+using usize = uint64_t;  // Rust usize on the 64-bit reference platform
+
+enum : int {
+  ORC_OK = 0,
+  ORC_E_OVERFLOW = 1,   // checked_add().unwrap() panic (mul_hash.rs:47-48, lib.rs:270)
+  ORC_E_OOB = 2,        // slice index panic on inner-dimension mismatch (mul_hash.rs:46,89,151)
+  ORC_E_ASSERT = 3,     // assert_eq!(curr, ...) (mul_hash.rs:190)
+  ORC_E_BADKEY = 4,     // debug_assert!(key != u32::MAX) (set.rs:110)
+};
+
+// linprobe/src/lib.rs:13-14
+constexpr uint32_t HASH_SCAL = 107;
+constexpr usize MIN_TABLE_SIZE = 16;
+
+// linprobe/src/lib.rs:28-31 (MulHasher::write_u32) + :20-22 (finish): hash = (i * 107 mod 2^32) as u64
+inline uint64_t mul_hash_u32(uint32_t i) { return (uint64_t)(uint32_t)(i * HASH_SCAL); }
+
+// usize::checked_next_power_of_two: smallest power of two >= x; next_power_of_two(0) == 1
+inline usize next_pow2(usize x) {
+  if (x <= 1) return 1;
+  usize p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+// linprobe/src/set.rs:38-43 / map.rs:33-38: max(16, 2 * next_power_of_two(capacity))
+inline usize table_size_for(usize capacity) { return std::max<usize>(2 * next_pow2(capacity), MIN_TABLE_SIZE); }
+
+// ---------------------------------------------------------------------------------------------
+// linprobe::HashSet  (linprobe/src/set.rs)
+// ---------------------------------------------------------------------------------------------
+struct HashSet {
+  std::vector<uint32_t> slots;
+  usize upper_bound = 0;
+  usize items = 0;
+
+  // set.rs:24-26 new() == with_capacity(MIN_TABLE_SIZE / 4); set.rs:37-54
+  HashSet() : HashSet(MIN_TABLE_SIZE / 4) {}
+  explicit HashSet(usize capacity) {
+    upper_bound = table_size_for(capacity);
+    slots.assign(upper_bound, UINT32_MAX);
+  }
+  // set.rs:55-64 — ONLY shrinks the logical bound (min with current)
+  void shrink_to(usize capacity) { upper_bound = std::min(table_size_for(capacity), upper_bound); }
+  usize len() const { return items; }  // set.rs:68-70
+  // set.rs:71-74
+  void clear() {
+    std::fill(slots.begin(), slots.begin() + upper_bound, UINT32_MAX);
+    items = 0;
+  }
+  // set.rs:128-160 insert_raw
+  static bool insert_raw(uint32_t* s, usize len, uint32_t key, uint64_t hash) {
+    usize index = (usize)hash & (len - 1);
+    for (;;) {
+      uint32_t& curr = s[index];
+      if (curr == key) return false;
+      if (curr == UINT32_MAX) {
+        curr = key;
+        return true;
+      }
+      index = (index + 1) & (len - 1);
+    }
+  }
+  // set.rs:77-107
+  void grow() {
+    if (upper_bound == slots.size()) slots.resize(slots.size() * 2, UINT32_MAX);
+    std::vector<uint32_t> keys;
+    keys.reserve(items);
+    for (usize i = 0; i < upper_bound; ++i)
+      if (slots[i] != UINT32_MAX) {
+        keys.push_back(slots[i]);
+        slots[i] = UINT32_MAX;
+      }
+    upper_bound *= 2;
+    for (uint32_t k : keys) insert_raw(slots.data(), upper_bound, k, mul_hash_u32(k));
+  }
+  // set.rs:108-124
+  void insert(uint32_t key) {
+    if (insert_raw(slots.data(), upper_bound, key, mul_hash_u32(key))) items += 1;
+    if (items > upper_bound / 2) grow();
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// linprobe::HashMap<u32, V>  (linprobe/src/map.rs)
+// ---------------------------------------------------------------------------------------------
+template <class V>
+struct HashMap {
+  struct Slot {
+    uint8_t tag;  // Option<(NonZeroU8, K, V)>: tag 0 == None (map.rs:14-15)
+    uint32_t k;
+    V v;
+  };
+  std::vector<Slot> slots;
+  usize capacity = 0;
+
+  // map.rs:32-48 with_capacity
+  explicit HashMap(usize cap) {
+    capacity = table_size_for(cap);
+    slots.assign(capacity, Slot{0, 0, V()});
+  }
+  // map.rs:49-58 — sets the logical capacity (mask); never grows (sized from symbolic)
+  void shrink_to(usize cap) { capacity = table_size_for(cap); }
+  // map.rs:67-97 entry + :106-120 and_modify / or_insert, fused:
+  //   first sighting stores t1 (NOT 0 + t1), later sightings do *t += t1   (mul_hash.rs:157-161)
+  template <class AddAssign>
+  void upsert(uint32_t key, V t1, AddAssign add_assign) {
+    usize index = (usize)mul_hash_u32(key) & (capacity - 1);
+    for (;;) {
+      Slot& s = slots[index];
+      if (s.tag && s.k == key) {
+        add_assign(s.v, t1);
+        return;
+      }
+      if (!s.tag) {
+        s = Slot{1, key, t1};
+        return;
+      }
+      index = (index + 1) & (capacity - 1);
+    }
+  }
+  // map.rs:59-63 drain: slots[..capacity] in index order, take()ing each
+  template <class F>
+  void drain(F f) {
+    for (usize i = 0; i < capacity; ++i)
+      if (slots[i].tag) {
+        f(slots[i].k, slots[i].v);
+        slots[i].tag = 0;
+      }
+  }
+};
+
+// Arithmetic of T as Rust does it.  f32/f64: plain IEEE mul then add (no contraction).  Integers stand
+// for std::num::Wrapping<i8> / Wrapping<i64> (tests.rs:358): two's-complement wrap.
+template <class T>
+inline T mul_t(T a, T b) {
+  if constexpr (std::is_integral_v<T>) {
+    using U = std::make_unsigned_t<T>;
+    return (T)(U)((U)a * (U)b);
+  } else {
+    return a * b;
+  }
+}
+template <class T>
+inline void add_assign_t(T& acc, T x) {
+  if constexpr (std::is_integral_v<T>) {
+    using U = std::make_unsigned_t<T>;
+    acc = (T)(U)((U)acc + (U)x);
+  } else {
+    acc = acc + x;
+  }
+}
+
+// spam_csr/src/lib.rs:267-274 checked_inclusive_scan: [0, v0, v0+v1, ...] with overflow check
+int checked_inclusive_scan(const usize* v, usize n, usize* out) {
+  usize sum = 0;
+  out[0] = 0;
+  for (usize i = 0; i < n; ++i) {
+    if (__builtin_add_overflow(sum, v[i], &sum)) return ORC_E_OVERFLOW;
+    out[i + 1] = sum;
+  }
+  return ORC_OK;
+}
+
+struct CsrView {
+  usize rows;
+  const usize* offsets;  // rows + 1
+  const usize* indices;  // nnz
+};
+
+template <class Fn>
+void scoped_spawn(const usize* rows_offset, usize tnum, Fn fn) {
+  // rayon::scope + one s.spawn per (tlo, thi) window (mul_hash.rs:72-76, :120-130).  Ranges are
+  // disjoint, so running them on real threads or one after another gives identical results.
+  std::vector<std::thread> th;
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  if (tnum <= 1 || hw == 1) {
+    for (usize t = 0; t < tnum; ++t) fn(t, rows_offset[t], rows_offset[t + 1]);
+    return;
+  }
+  for (usize t = 0; t < tnum; ++t) th.emplace_back([=] { fn(t, rows_offset[t], rows_offset[t + 1]); });
+  for (auto& x : th) x.join();
+}
+
+// spam_csr/src/mul_hash.rs:38-64 rows_to_threads
+int rows_to_threads(CsrView a, CsrView b, usize tnum, usize* row_nz, usize* rows_offset) {
+  // :39-50 per-row intermediate-product count, checked
+  for (usize i = 0; i < a.rows; ++i) {
+    usize sum = 0;
+    for (usize p = a.offsets[i]; p < a.offsets[i + 1]; ++p) {
+      usize k = a.indices[p];
+      if (k + 1 > b.rows) return ORC_E_OOB;  // rhs.offsets[k + 1] out of bounds
+      if (__builtin_add_overflow(sum, b.offsets[k + 1] - b.offsets[k], &sum)) return ORC_E_OVERFLOW;
+    }
+    row_nz[i] = sum;
+  }
+  // :51-52
+  std::vector<usize> ps(a.rows + 1);
+  if (int e = checked_inclusive_scan(row_nz, a.rows, ps.data())) return e;
+  usize total = ps.back();
+  // :54-55 tnum = num_cpus::get(); average = ceil(total / tnum)
+  usize average = total / tnum + (total % tnum != 0);
+  // :56-62 rows_offset = [0, partition_point(ps, x <= average*tid) - 1 for tid in 1..tnum, rows]
+  rows_offset[0] = 0;
+  for (usize tid = 1; tid < tnum; ++tid) {
+    usize bound = average * tid;
+    usize pp = (usize)(std::partition_point(ps.begin(), ps.end(), [&](usize x) { return x <= bound; }) - ps.begin());
+    rows_offset[tid] = pp - 1;
+  }
+  rows_offset[tnum] = a.rows;
+  return ORC_OK;
+}
+
+// spam_csr/src/mul_hash.rs:66-103 mul_hash_symbolic
+int mul_hash_symbolic(CsrView a, CsrView b, usize* row_nz, const usize* rows_offset, usize tnum) {
+  std::vector<int> err(tnum, ORC_OK);
+  scoped_spawn(rows_offset, tnum, [&](usize t, usize tlo, usize thi) {
+    HashSet hs;  // :77 one set per spawned task, reused across its rows
+    for (usize r = tlo; r < thi; ++r) {
+      if (row_nz[r] == 0) continue;  // :84-86
+      hs.shrink_to(row_nz[r]);       // :87
+      for (usize p = a.offsets[r]; p < a.offsets[r + 1]; ++p) {
+        usize k = a.indices[p];
+        for (usize q = b.offsets[k]; q < b.offsets[k + 1]; ++q) {
+          uint32_t j = (uint32_t)b.indices[q];  // :92 `j as u32` truncation
+          if (j == UINT32_MAX) err[t] = ORC_E_BADKEY;
+          hs.insert(j);
+        }
+      }
+      row_nz[r] = hs.len();  // :95
+      hs.clear();            // :96
+    }
+  });
+  for (int e : err)
+    if (e) return e;
+  return ORC_OK;
+}
+
+// spam_csr/src/mul_hash.rs:106-201 mul_hash_numeric::<B1, B2>
+template <class T>
+int mul_hash_numeric(CsrView a, const T* a_vals, CsrView b, const T* b_vals, const usize* row_nz,
+                     const usize* rows_offset, usize tnum, bool b2_sort, usize* offsets, usize* indices, T* vals) {
+  if (int e = checked_inclusive_scan(row_nz, a.rows, offsets)) return e;  // :117
+  std::vector<int> err(tnum, ORC_OK);
+  scoped_spawn(rows_offset, tnum, [&](usize t, usize tlo, usize thi) {
+    // :131-133 capacity = max row nnz in this range
+    usize capacity = 0;
+    for (usize r = tlo; r < thi; ++r) capacity = std::max(capacity, row_nz[r]);
+    HashMap<T> hm(capacity);
+    usize* tindices = indices + offsets[tlo];  // :125-128 disjoint per-thread output slices
+    T* tvals = vals + offsets[tlo];
+    usize curr = 0;
+    std::vector<std::pair<uint32_t, T>> row;
+    for (usize r = tlo; r < thi; ++r) {
+      if (row_nz[r] == 0) continue;  // :141-143
+      hm.shrink_to(row_nz[r]);       // :144
+      for (usize p = a.offsets[r]; p < a.offsets[r + 1]; ++p) {  // :145-149 A row in storage order
+        usize k = a.indices[p];
+        T tv = a_vals[p];
+        for (usize q = b.offsets[k]; q < b.offsets[k + 1]; ++q) {  // :150-154 B row in storage order
+          T t1 = mul_t(tv, b_vals[q]);                            // :154 t * t1
+          hm.upsert((uint32_t)b.indices[q], t1, [](T& acc, T x) { add_assign_t(acc, x); });  // :157-161
+        }
+      }
+      if (b2_sort) {  // :164-175 collect, sort_unstable_by_key(col) — keys are distinct so order is unique
+        row.clear();
+        hm.drain([&](uint32_t c, T v) { row.emplace_back(c, v); });
+        std::sort(row.begin(), row.end(), [](auto& x, auto& y) { return x.first < y.first; });
+        for (auto& cv : row) {
+          tindices[curr] = cv.first;
+          tvals[curr] = cv.second;
+          curr += 1;
+        }
+      } else {  // :176-186 slot order
+        hm.drain([&](uint32_t c, T v) {
+          tindices[curr] = c;
+          tvals[curr] = v;
+          curr += 1;
+        });
+      }
+    }
+    if (curr != offsets[thi] - offsets[tlo]) err[t] = ORC_E_ASSERT;  // :190
+  });
+  for (int e : err)
+    if (e) return e;
+  return ORC_OK;
+}
+
+// SpMV — ABSENT from the reference.  Definition: y = A.mul_hash(X) with X the
+// cols(A) x 1 matrix of x.  Following mul_hash.rs:145-163 with the single key 0:
+//   y_i = ((a_i,k0 * x_k0) + a_i,k1 * x_k1) + ...   left to right in A's storage order, the first
+//   product stored (not added to 0), separate multiply and add.  Rows without entries give 0.
+template <class T>
+void spmv(CsrView a, const T* a_vals, const T* x, T* y, unsigned nthreads) {
+  auto body = [&](usize lo, usize hi) {
+    for (usize r = lo; r < hi; ++r) {
+      usize p = a.offsets[r], e = a.offsets[r + 1];
+      if (p == e) {
+        y[r] = T(0);
+        continue;
+      }
+      T acc = mul_t(a_vals[p], x[a.indices[p]]);
+      for (++p; p < e; ++p) add_assign_t(acc, mul_t(a_vals[p], x[a.indices[p]]));
+      y[r] = acc;
+    }
+  };
+  if (nthreads <= 1) return body(0, a.rows);
+  // contiguous row ranges balanced by nnz; per-row arithmetic is independent of the split
+  std::vector<std::thread> th;
+  usize nnz = a.offsets[a.rows];
+  usize lo = 0;
+  for (unsigned t = 0; t < nthreads; ++t) {
+    usize target = nnz / nthreads * (t + 1);
+    usize hi = (t + 1 == nthreads)
+                   ? a.rows
+                   : (usize)(std::upper_bound(a.offsets, a.offsets + a.rows + 1, target) - a.offsets) - 1;
+    hi = std::max(hi, lo);
+    th.emplace_back(body, lo, hi);
+    lo = hi;
+  }
+  for (auto& x_ : th) x_.join();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C entry points for ctypes (tests/, bench.py cpu_baseline).
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+unsigned orc_hardware_threads(void) { return std::max(1u, std::thread::hardware_concurrency()); }
+
+uint64_t orc_table_size_for(uint64_t capacity) { return table_size_for(capacity); }
+uint64_t orc_hash_u32(uint32_t key) { return mul_hash_u32(key); }
+
+int orc_checked_inclusive_scan(const uint64_t* v, uint64_t n, uint64_t* out) { return checked_inclusive_scan(v, n, out); }
+
+// Drive one linprobe::HashSet exactly as one symbolic row does: new(); shrink_to(hint); insert keys.
+// Returns len(); writes upper_bound and the first upper_bound slots (caller gives room for `slots_cap`).
+uint64_t orc_hashset_run(const uint32_t* keys, uint64_t n, uint64_t shrink_hint, uint32_t* slots_out,
+                         uint64_t slots_cap, uint64_t* upper_bound_out) {
+  HashSet hs;
+  hs.shrink_to(shrink_hint);
+  for (uint64_t i = 0; i < n; ++i) hs.insert(keys[i]);
+  *upper_bound_out = hs.upper_bound;
+  for (uint64_t i = 0; i < std::min<uint64_t>(hs.upper_bound, slots_cap); ++i) slots_out[i] = hs.slots[i];
+  return hs.len();
+}
+
+// Drive one linprobe::HashMap<u32, f64> as one numeric row does: with_capacity(cap); shrink_to(row_nz);
+// upsert (key, val) pairs; drain.  Returns the number of drained entries.
+uint64_t orc_hashmap_run_f64(const uint32_t* keys, const double* vals, uint64_t n, uint64_t with_capacity,
+                             uint64_t row_nz, uint32_t* keys_out, double* vals_out) {
+  HashMap<double> hm(with_capacity);
+  hm.shrink_to(row_nz);
+  for (uint64_t i = 0; i < n; ++i) hm.upsert(keys[i], vals[i], [](double& a, double x) { a = a + x; });
+  uint64_t m = 0;
+  hm.drain([&](uint32_t c, double v) {
+    keys_out[m] = c;
+    vals_out[m] = v;
+    ++m;
+  });
+  return m;
+}
+
+int orc_rows_to_threads(uint64_t a_rows, const uint64_t* a_off, const uint64_t* a_idx, uint64_t b_rows,
+                        const uint64_t* b_off, uint64_t tnum, uint64_t* row_nz, uint64_t* rows_offset) {
+  return rows_to_threads(CsrView{a_rows, a_off, a_idx}, CsrView{b_rows, b_off, nullptr}, tnum, row_nz, rows_offset);
+}
+
+int orc_mul_hash_symbolic(uint64_t a_rows, const uint64_t* a_off, const uint64_t* a_idx, uint64_t b_rows,
+                          const uint64_t* b_off, const uint64_t* b_idx, uint64_t* row_nz,
+                          const uint64_t* rows_offset, uint64_t tnum) {
+  return mul_hash_symbolic(CsrView{a_rows, a_off, a_idx}, CsrView{b_rows, b_off, b_idx}, row_nz, rows_offset, tnum);
+}
+
+#define ORC_DEFINE_TYPED(SUFFIX, T)                                                                               \
+  int orc_mul_hash_numeric_##SUFFIX(uint64_t a_rows, const uint64_t* a_off, const uint64_t* a_idx, const T* a_val, \
+                                    uint64_t b_rows, const uint64_t* b_off, const uint64_t* b_idx, const T* b_val, \
+                                    const uint64_t* row_nz, const uint64_t* rows_offset, uint64_t tnum,            \
+                                    int sort_rows, uint64_t* offsets, uint64_t* indices, T* vals) {                \
+    return mul_hash_numeric<T>(CsrView{a_rows, a_off, a_idx}, a_val, CsrView{b_rows, b_off, b_idx}, b_val, row_nz, \
+                               rows_offset, tnum, sort_rows != 0, offsets, indices, vals);                         \
+  }                                                                                                                \
+  void orc_spmv_##SUFFIX(uint64_t a_rows, const uint64_t* a_off, const uint64_t* a_idx, const T* a_val,            \
+                         const T* x, T* y, unsigned nthreads) {                                                    \
+    spmv<T>(CsrView{a_rows, a_off, a_idx}, a_val, x, y, nthreads);                                                 \
+  }
+
+ORC_DEFINE_TYPED(f64, double)
+ORC_DEFINE_TYPED(f32, float)
+ORC_DEFINE_TYPED(i8, int8_t)
+ORC_DEFINE_TYPED(i64, int64_t)
+
+}  // extern "C"

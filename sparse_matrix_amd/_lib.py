@@ -1,0 +1,114 @@
+"""ctypes binding of libspam_hip.so (the C ABI in include/spam_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, this raises.  The oracle
+(``oracle/``) is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspam_hip.so")
+
+SPAM_OK = 0
+SPAM_F32, SPAM_F64 = 0, 1
+ERR_NAMES = {1: "SPAM_E_INVALID", 2: "SPAM_E_INDEX_RANGE", 3: "SPAM_E_OOM", 4: "SPAM_E_HIP",
+             5: "SPAM_E_OVERFLOW", 6: "SPAM_E_UNSUPPORTED", 7: "SPAM_E_DTYPE"}
+
+
+class SpamError(RuntimeError):
+    """Non-zero status from libspam_hip.so — where the Rust reference would panic."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class SpgemmStats(C.Structure):
+    _fields_ = [("rows", C.c_uint64), ("inner", C.c_uint64), ("cols", C.c_uint64),
+                ("nnz_a", C.c_uint64), ("nnz_b", C.c_uint64), ("nnz_c", C.c_uint64),
+                ("flops_f", C.c_uint64),
+                ("rows_sym_bin", C.c_uint64 * 8), ("rows_num_bin", C.c_uint64 * 8),
+                ("heavy_items", C.c_uint64),
+                ("ms_flops", C.c_float), ("ms_symbolic", C.c_float), ("ms_alloc", C.c_float),
+                ("ms_numeric", C.c_float), ("ms_total", C.c_float)]
+
+    def asdict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+# every symbol include/spam_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_U64 = C.c_uint64
+_PP = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "spam_hip_init": (C.c_int, [C.c_int]),
+    "spam_hip_set_stream": (C.c_int, [_P]),
+    "spam_hip_synchronize": (C.c_int, []),
+    "spam_last_error": (C.c_char_p, []),
+    "spam_version": (C.c_int, []),
+    "spam_csr_upload_f64": (C.c_int, [_U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
+    "spam_csr_upload_f32": (C.c_int, [_U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
+    "spam_csr_from_device": (C.c_int, [C.c_int, _U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
+    "spam_csr_row_block": (C.c_int, [_P, _U64, _U64, _PP]),
+    "spam_csr_dims": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64), C.POINTER(C.c_int),
+                                C.POINTER(C.c_int)]),
+    "spam_csr_device_ptrs": (C.c_int, [_P, _PP, _PP, _PP]),
+    "spam_csr_download_f64": (C.c_int, [_P, _P, _P, _P]),
+    "spam_csr_download_f32": (C.c_int, [_P, _P, _P, _P]),
+    "spam_csr_invariants": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "spam_csr_free": (None, [_P]),
+    "spam_spmv_f64": (C.c_int, [_P, _P, _P]),
+    "spam_spmv_f32": (C.c_int, [_P, _P, _P]),
+    "spam_spmv_dev": (C.c_int, [_P, _P, _P]),
+    "spam_spgemm_symbolic": (C.c_int, [_P, _P, _PP, C.POINTER(_U64)]),
+    "spam_spgemm_numeric_f64": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "spam_spgemm_numeric_f32": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "spam_spgemm_numeric_dev": (C.c_int, [_P, C.c_int, _PP]),
+    "spam_spgemm_plan_stats": (C.c_int, [_P, C.POINTER(SpgemmStats)]),
+    "spam_spgemm_plan_free": (None, [_P]),
+    "spam_spgemm_dev": (C.c_int, [_P, _P, C.c_int, _PP, C.POINTER(SpgemmStats)]),
+    "spam_rows_to_parts": (C.c_int, [_P, _P, _U64, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libspam_hip.so and bind every declared symbol.  Raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  sparse_matrix_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status: int):
+    if status != SPAM_OK:
+        raise SpamError(status, load().spam_last_error().decode())
+
+
+_initialised = False
+
+
+def ensure_device(device: int | None = None):
+    """spam_hip_init once per process (device defaults to LOCAL_RANK or 0)."""
+    global _initialised
+    if not _initialised or device is not None:
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        check(load().spam_hip_init(device))
+        _initialised = True

@@ -1,0 +1,266 @@
+"""Host-side mirror of the reference's ``spam_csr::CsrMatrix<T, IS_SORTED>`` over the HIP back end.
+
+Same names, argument meaning and error behaviour as the Rust type (spam_csr/src/lib.rs:25-32,151-197,
+292-358) and the ``Matrix`` trait (spam_matrix/src/lib.rs:15-27) for everything on the SpMV / SpGEMM path;
+``mul_hash`` (spam_csr/src/mul_hash.rs:13-36) and the new ``spmv`` run on the GPU through the C ABI in
+include/spam_hip.h.  Element-wise get/set/transpose/add/sub are off the hot path and stay with the
+reference's CPU code — they are not provided here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SPAM_F32, SPAM_F64, SpamError, SpgemmStats, check
+
+_NP2DT = {np.dtype(np.float32): SPAM_F32, np.dtype(np.float64): SPAM_F64}
+_DT2NP = {SPAM_F32: np.float32, SPAM_F64: np.float64}
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceCsr:
+    """An uploaded / device-resident matrix (opaque ``spam_csr*``)."""
+
+    def __init__(self, handle, keepalive=None):
+        self._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        self._keep = keepalive  # parent handles / torch tensors the view borrows from
+
+    # -- construction -------------------------------------------------------------------------
+    @classmethod
+    def upload(cls, rows, cols, offsets, indices, vals, is_sorted):
+        _lib.ensure_device()
+        L = _lib.load()
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        indices = np.ascontiguousarray(indices, dtype=np.uint64)
+        vals = np.ascontiguousarray(vals)
+        if vals.dtype not in _NP2DT:
+            raise TypeError(f"GPU path supports f32/f64 values, not {vals.dtype}")
+        if offsets.size != rows + 1:
+            raise SpamError(1, "len(offsets) != rows + 1 (invariant 2)")
+        if indices.size != vals.size:
+            raise SpamError(1, "len(indices) != len(vals) (invariant 1)")
+        h = C.c_void_p()
+        fn = L.spam_csr_upload_f64 if vals.dtype == np.float64 else L.spam_csr_upload_f32
+        check(fn(rows, cols, vals.size, _vp(offsets), _vp(indices), _vp(vals), int(bool(is_sorted)), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_device(cls, dtype, rows, cols, nnz, row_ptr_ptr, col_idx_ptr, vals_ptr, is_sorted, keepalive=None):
+        """Wrap device arrays (u64 row_ptr, u32 col_idx, T vals) without copying."""
+        _lib.ensure_device()
+        h = C.c_void_p()
+        check(_lib.load().spam_csr_from_device(dtype, rows, cols, nnz, C.c_void_p(row_ptr_ptr), C.c_void_p(col_idx_ptr),
+                                               C.c_void_p(vals_ptr), int(bool(is_sorted)), C.byref(h)))
+        return cls(h, keepalive)
+
+    @classmethod
+    def from_torch(cls, rows, cols, row_ptr, col_idx, vals, is_sorted):
+        """torch CUDA tensors: row_ptr int64[rows+1], col_idx int32[nnz], vals f32/f64[nnz]."""
+        import torch
+
+        assert row_ptr.dtype == torch.int64 and col_idx.dtype == torch.int32
+        dt = SPAM_F64 if vals.dtype == torch.float64 else SPAM_F32
+        return cls.from_device(dt, rows, cols, int(col_idx.numel()), row_ptr.data_ptr(), col_idx.data_ptr(),
+                               vals.data_ptr(), is_sorted, keepalive=(row_ptr, col_idx, vals))
+
+    def row_block(self, lo: int, hi: int) -> "DeviceCsr":
+        h = C.c_void_p()
+        check(_lib.load().spam_csr_row_block(self._h, lo, hi, C.byref(h)))
+        return DeviceCsr(h, keepalive=self)
+
+    # -- queries ------------------------------------------------------------------------------
+    def dims(self):
+        r, c, n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        dt, srt = C.c_int(), C.c_int()
+        check(_lib.load().spam_csr_dims(self._h, C.byref(r), C.byref(c), C.byref(n), C.byref(dt), C.byref(srt)))
+        return r.value, c.value, n.value, dt.value, bool(srt.value)
+
+    def device_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(_lib.load().spam_csr_device_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def invariants(self) -> bool:
+        ok = C.c_int()
+        check(_lib.load().spam_csr_invariants(self._h, C.byref(ok)))
+        return bool(ok.value)
+
+    def download(self):
+        rows, cols, nnz, dt, _ = self.dims()
+        offsets = np.empty(rows + 1, dtype=np.uint64)
+        indices = np.empty(nnz, dtype=np.uint64)
+        vals = np.empty(nnz, dtype=_DT2NP[dt])
+        fn = _lib.load().spam_csr_download_f64 if dt == SPAM_F64 else _lib.load().spam_csr_download_f32
+        check(fn(self._h, _vp(offsets), _vp(indices), _vp(vals)))
+        return offsets, indices, vals
+
+    # -- products -----------------------------------------------------------------------------
+    def spmv_dev(self, x_ptr: int, y_ptr: int):
+        check(_lib.load().spam_spmv_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def spmv(self, x: np.ndarray) -> np.ndarray:
+        rows, cols, _, dt, _ = self.dims()
+        x = np.ascontiguousarray(x, dtype=_DT2NP[dt])
+        if x.size != cols:
+            raise SpamError(1, f"x has {x.size} entries, A has {cols} columns")
+        y = np.empty(rows, dtype=_DT2NP[dt])
+        fn = _lib.load().spam_spmv_f64 if dt == SPAM_F64 else _lib.load().spam_spmv_f32
+        check(fn(self._h, _vp(x), _vp(y)))
+        return y
+
+    def spgemm(self, rhs: "DeviceCsr", sort_rows: bool = False):
+        """C = self * rhs, device-resident.  Returns (DeviceCsr, stats dict)."""
+        h = C.c_void_p()
+        st = SpgemmStats()
+        check(_lib.load().spam_spgemm_dev(self._h, rhs._h, int(bool(sort_rows)), C.byref(h), C.byref(st)))
+        return DeviceCsr(h), st.asdict()
+
+    def rows_to_parts(self, rhs: "DeviceCsr", nparts: int):
+        rows = self.dims()[0]
+        flops = np.empty(rows, dtype=np.uint64)
+        offs = np.empty(nparts + 1, dtype=np.uint64)
+        check(_lib.load().spam_rows_to_parts(self._h, rhs._h, nparts, _vp(flops), _vp(offs)))
+        return flops, offs
+
+    def free(self):
+        if self._h:
+            _lib.load().spam_csr_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CsrMatrix:
+    """``CsrMatrix<T, IS_SORTED>``: host Vecs in the reference's layout, products on the GPU."""
+
+    def __init__(self, rows, cols, vals, indices, offsets, is_sorted: bool):
+        if rows <= 0 or cols <= 0:
+            raise ValueError("rows and cols are NonZeroUsize (spam_csr/src/lib.rs:27-28)")
+        self._rows, self._cols = int(rows), int(cols)
+        self.vals = np.ascontiguousarray(vals)
+        self.indices = np.ascontiguousarray(indices, dtype=np.uint64)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.is_sorted = bool(is_sorted)
+        self._dev = None
+
+    # -- Matrix trait (spam_matrix/src/lib.rs:15-27) ----------------------------------------
+    @classmethod
+    def new(cls, shape, dtype=np.float64, is_sorted=True):
+        rows, cols = shape
+        return cls(rows, cols, np.empty(0, dtype), np.empty(0, np.uint64), np.zeros(rows + 1, np.uint64), is_sorted)
+
+    @classmethod
+    def new_square(cls, n, dtype=np.float64, is_sorted=True):
+        return cls.new((n, n), dtype, is_sorted)
+
+    @classmethod
+    def identity(cls, n, dtype=np.float64, is_sorted=True):
+        """spam_csr/src/lib.rs:177-185"""
+        return cls(n, n, np.ones(n, dtype), np.arange(n, dtype=np.uint64), np.arange(n + 1, dtype=np.uint64), is_sorted)
+
+    def rows(self):
+        return self._rows
+
+    def cols(self):
+        return self._cols
+
+    def nnz(self):
+        return int(self.indices.size)
+
+    def invariants(self) -> bool:
+        """Invariants 1-7 (spam_csr/src/lib.rs:47-81) — 1 and 2 on the host, the rest on the device."""
+        if self.indices.size != self.vals.size or self.offsets.size != self._rows + 1:
+            return False
+        try:
+            return self.device().invariants()
+        except SpamError as e:
+            if e.code in (1, 2):
+                return False
+            raise
+
+    # -- constructors from DOK (spam_csr/src/lib.rs:315-358) --------------------------------
+    @classmethod
+    def from_dok(cls, shape, entries: dict, dtype=np.float64, rng=None):
+        """``From<DokMatrix>`` (sorted rows) or, with ``rng``, ``from_dok(dok, rng)`` (shuffled rows).
+
+        ``entries`` maps (row, col) -> value; zeros are dropped as DokMatrix::set_element does
+        (spam_dok/src/lib.rs:171-175)."""
+        rows, cols = shape
+        items = [(k, v) for k, v in entries.items() if v != 0]
+        for (i, j), _ in items:
+            if not (0 <= i < rows and 0 <= j < cols):
+                raise IndexError("IndexError")  # spam_matrix::IndexError
+        if rng is None:
+            items.sort(key=lambda kv: kv[0])  # BTreeMap order: (row, col) lexicographic
+        else:
+            perm = rng.permutation(len(items))
+            items = [items[p] for p in perm]
+            items.sort(key=lambda kv: kv[0][0])  # stable by row only
+        counts = np.zeros(rows, dtype=np.uint64)
+        for (i, _), _ in items:
+            counts[i] += 1
+        offsets = np.zeros(rows + 1, dtype=np.uint64)
+        np.cumsum(counts, out=offsets[1:])
+        indices = np.array([j for (_, j), _ in items], dtype=np.uint64)
+        vals = np.array([v for _, v in items], dtype=dtype)
+        return cls(rows, cols, vals, indices, offsets, is_sorted=rng is None)
+
+    def to_dok(self) -> dict:
+        """``From<CsrMatrix> for DokMatrix`` (spam_csr/src/lib.rs:375-384): zeros dropped."""
+        out = {}
+        off = self.offsets.astype(np.int64)
+        for r in range(self._rows):
+            for p in range(off[r], off[r + 1]):
+                v = self.vals[p]
+                key = (r, int(self.indices[p]))
+                if v != 0:
+                    out[key] = v
+                else:
+                    out.pop(key, None)
+        return out
+
+    # -- device ------------------------------------------------------------------------------
+    def device(self) -> DeviceCsr:
+        if self._dev is None:
+            self._dev = DeviceCsr.upload(self._rows, self._cols, self.offsets, self.indices, self.vals, self.is_sorted)
+        return self._dev
+
+    # -- the hot path ------------------------------------------------------------------------
+    def mul_hash(self, rhs: "CsrMatrix", sort_output: bool = False) -> "CsrMatrix":
+        """``mul_hash::<B1, B2>`` (spam_csr/src/mul_hash.rs:13-36); ``sort_output`` is B2.
+
+        Two phases exactly like the reference: symbolic gives nnz, the caller-side Vecs are allocated to
+        that capacity (mul_hash.rs:119), numeric fills them."""
+        L = _lib.load()
+        a, b = self.device(), rhs.device()
+        plan = C.c_void_p()
+        nnz = C.c_uint64()
+        check(L.spam_spgemm_symbolic(a._h, b._h, C.byref(plan), C.byref(nnz)))
+        try:
+            offsets = np.empty(self._rows + 1, dtype=np.uint64)
+            indices = np.empty(nnz.value, dtype=np.uint64)
+            vals = np.empty(nnz.value, dtype=self.vals.dtype)
+            fn = L.spam_spgemm_numeric_f64 if self.vals.dtype == np.float64 else L.spam_spgemm_numeric_f32
+            check(fn(plan, int(bool(sort_output)), _vp(offsets), _vp(indices), _vp(vals)))
+        finally:
+            L.spam_spgemm_plan_free(plan)
+        return CsrMatrix(self._rows, rhs._cols, vals, indices, offsets, is_sorted=sort_output)
+
+    def __mul__(self, rhs):
+        """``impl Mul for &CsrMatrix`` -> ``CsrMatrix<T, false>`` (spam_csr/src/lib.rs:292-297)."""
+        return self.mul_hash(rhs, sort_output=False)
+
+    __matmul__ = __mul__
+
+    def spmv(self, x) -> np.ndarray:
+        """y = A x (absent upstream; defined as mul_hash with an n x 1 rhs)."""
+        return self.device().spmv(np.asarray(x))

@@ -1,0 +1,114 @@
+// Internal declarations shared by the HIP translation units of libspam_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <new>
+
+#include "../../include/spam_hip.h"
+
+namespace spam {
+
+constexpr uint32_t EMPTY_KEY = 0xFFFFFFFFu;  // linprobe's sentinel (linprobe/src/set.rs:45)
+constexpr uint32_t HASH_SCAL = 107u;         // linprobe/src/lib.rs:13
+constexpr uint32_t MIN_TABLE = 16u;          // linprobe/src/lib.rs:14
+
+// ---- error plumbing ---------------------------------------------------------------------------
+int set_error(int code, const char* fmt, ...);
+void clear_error();
+
+#define SPAM_HIP_TRY(expr)                                                                            \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess) {                                                                           \
+      int _c = (_e == hipErrorOutOfMemory) ? SPAM_E_OOM : SPAM_E_HIP;                                 \
+      return ::spam::set_error(_c, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                               __LINE__);                                                             \
+    }                                                                                                 \
+  } while (0)
+
+#define SPAM_TRY(expr)          \
+  do {                          \
+    int _s = (expr);            \
+    if (_s != SPAM_OK) return _s; \
+  } while (0)
+
+#define SPAM_CHECK_LAUNCH() SPAM_HIP_TRY(hipGetLastError())
+
+hipStream_t stream();
+
+// RAII device buffer (frees on scope exit unless released)
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { reset(); }
+  int alloc(size_t n) {
+    reset();
+    bytes = n;
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      (void)hipGetLastError();
+      return set_error(SPAM_E_OOM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    return SPAM_OK;
+  }
+  void reset() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  void* release() {
+    void* q = p;
+    p = nullptr;
+    bytes = 0;
+    return q;
+  }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+struct SpmvPlan;
+
+}  // namespace spam
+
+// The opaque handle of the C ABI.
+struct spam_csr {
+  uint64_t rows = 0, cols = 0, nnz = 0;
+  int dtype = SPAM_F64;
+  int is_sorted = 0;
+  uint64_t* row_ptr = nullptr;    // u64[rows+1]
+  uint32_t* row_ptr32 = nullptr;  // u32[rows+1], present iff nnz < 2^32 (SpMV reads 4-byte offsets)
+  uint32_t* col_idx = nullptr;    // u32[nnz]
+  void* vals = nullptr;           // T[nnz]
+  bool owns_row_ptr = false, owns_row_ptr32 = false, owns_col_val = false;
+  spam::SpmvPlan* spmv_plan = nullptr;  // built on first SpMV (row -> tile map), property of row_ptr only
+};
+
+namespace spam {
+
+inline size_t dtype_size(int dtype) { return dtype == SPAM_F32 ? 4 : 8; }
+
+// ---- device primitives (spam_scan.hip) ----------------------------------------------------------
+// out[0] = 0, out[i+1] = sum(in[0..i]) for i < n, u64 accumulation (checked_inclusive_scan's shape,
+// spam_csr/src/lib.rs:267-274).  tmp must hold scan_tmp_bytes(n).
+size_t scan_tmp_bytes(uint64_t n);
+int scan_u32_to_u64(const uint32_t* d_in, uint64_t n, uint64_t* d_out, void* d_tmp, hipStream_t s);
+int scan_u64_to_u64(const uint64_t* d_in, uint64_t n, uint64_t* d_out, void* d_tmp, hipStream_t s);
+// *d_flag |= 1 if any partial sum wrapped (checked_add overflow)
+int narrow_row_ptr(const uint64_t* d_in, uint64_t n, uint32_t* d_out, hipStream_t s);
+
+// ---- SpMV (spam_spmv.hip) ------------------------------------------------------------------------
+void spmv_plan_free(SpmvPlan* p);
+int spmv_launch(const spam_csr* a, const void* d_x, void* d_y, hipStream_t s);
+
+}  // namespace spam

@@ -1,0 +1,913 @@
+// spam_spgemm.hip — two-phase hash SpGEMM C = A B for gfx950.
+//
+// Reference counterpart: CsrMatrix::mul_hash (spam_csr/src/mul_hash.rs:13-201) with its linprobe
+// accumulator (linprobe/src/{lib,set,map}.rs):
+//   rows_to_threads  :38-64   -> spgemm_flops_kernel (+ host partition in spam_rows_to_parts)
+//   mul_hash_symbolic:66-103  -> sym_hash_kernel<G,S,TABLE> (LDS linprobe set, atomicCAS claim) and
+//                                sym_heavy_kernel (dense byte flags over 131072-column chunks in LDS)
+//   checked_inclusive_scan (lib.rs:267-274) -> scan_u32_to_u64
+//   mul_hash_numeric :106-201 -> num_hash_kernel<T,G,S,TABLE> (LDS linprobe map: u32 keys + T values,
+//                                atomicCAS claim + LDS atomic add) and num_heavy_kernel (dense T
+//                                accumulator + byte flags over 16384-column chunks in LDS)
+//   B2 (sort rows)   :164-175 -> sort_rows_kernel (bitonic in LDS); heavy rows come out sorted anyway
+//
+// Where the CPU code gives each thread a contiguous flop-balanced row range (mul_hash.rs:52-62), the GPU
+// bins rows by work: by F (intermediate products) for the symbolic pass, by nnz(C_i) for the numeric pass.
+// A bin fixes the lanes per row (16 / 64 / 256 / 1024) and the LDS table size, keeping linprobe's hash
+// (key * 107) & (size - 1), its sentinel u32::MAX and its sizing max(16, 2 * next_pow2(n)).
+// Rows whose table would not fit LDS take the "heavy" path: the column range is cut into chunks whose
+// dense accumulator does fit LDS, and B's sorted rows are pre-split at the chunk boundaries (bpos) so a
+// (row, chunk) work item touches only its own products.  No MFMA: nothing here is a dense contraction.
+//
+// Output order with sort_rows = 0: hash-path rows are emitted in THIS table's slot order (parallel claims
+// permute keys inside a collision run relative to the reference's sequential insertion), heavy rows sorted.
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "spam_internal.hpp"
+
+namespace spam {
+
+// ---- geometry -------------------------------------------------------------------------------------
+constexpr int CW_SHIFT = 14;
+constexpr uint32_t CW = 1u << CW_SHIFT;         // numeric chunk: 16384 columns (128 KB of f64 + 16 KB flags)
+constexpr int SCW_SHIFT = 17;
+constexpr uint32_t SCW = 1u << SCW_SHIFT;       // symbolic chunk: 131072 byte flags (128 KB)
+constexpr int SC_PER = SCW / CW;                // numeric chunks per symbolic chunk (8)
+
+constexpr int NSYM = 4;                         // symbolic bins by F
+constexpr uint64_t SYM_MAX[NSYM - 1] = {64, 512, 4096};
+constexpr int NNUM = 5;                         // numeric bins by nnz(C_i)
+constexpr uint64_t NUM_MAX[NNUM - 1] = {64, 512, 2048, 4096};
+
+struct BinLimits {
+  uint64_t max[7];
+  int nbins;  // bins 0..nbins-2 have max[], bin nbins-1 takes the rest; key 0 -> no bin
+};
+
+__device__ __forceinline__ uint32_t next_pow2_u32(uint32_t x) { return x <= 1 ? 1u : 1u << (32 - __clz(x - 1)); }
+// linprobe sizing: max(16, 2 * next_power_of_two(n))  (set.rs:38-43, map.rs:33-38)
+__device__ __forceinline__ uint32_t table_size_for(uint32_t n) {
+  uint32_t t = 2u * next_pow2_u32(n);
+  return t < MIN_TABLE ? MIN_TABLE : t;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ---- L1: per-row intermediate-product count (mul_hash.rs:39-50) -------------------------------------
+// One wavefront per row; B.row_ptr gathers are the traffic.  total[0] += F, total[1] |= overflow.
+__global__ __launch_bounds__(256) void spgemm_flops_kernel(const uint64_t* __restrict__ a_rp,
+                                                          const uint32_t* __restrict__ a_col,
+                                                          const uint64_t* __restrict__ b_rp, uint32_t rows,
+                                                          uint64_t* __restrict__ flops,
+                                                          unsigned long long* __restrict__ total) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint64_t mine = 0;
+  for (uint32_t r = wave; r < rows; r += nwaves) {
+    const uint64_t s = a_rp[r], e = a_rp[r + 1];
+    uint64_t f = 0;
+    for (uint64_t p = s + lane; p < e; p += 64) {
+      const uint32_t k = a_col[p];
+      f += b_rp[k + 1] - b_rp[k];
+    }
+    f = wave_sum_u64(f);
+    if (lane == 0) {
+      flops[r] = f;
+      mine += f;
+    }
+  }
+  __shared__ unsigned long long bsum;
+  if (threadIdx.x == 0) bsum = 0;
+  __syncthreads();
+  if (lane == 0 && mine) atomicAdd(&bsum, (unsigned long long)mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && bsum) {
+    unsigned long long old = atomicAdd(&total[0], bsum);
+    if (old + bsum < old) atomicOr(&total[1], 1ull);  // checked_add overflow (mul_hash.rs:47-48, lib.rs:270)
+  }
+}
+
+// ---- row binning ------------------------------------------------------------------------------------
+// lists[b * rows + i] = i-th row of bin b (order inside a bin is unspecified and does not affect results).
+template <class KeyT>
+__global__ __launch_bounds__(256) void bin_rows_kernel(const KeyT* __restrict__ key, uint32_t rows, BinLimits lim,
+                                                      uint32_t* __restrict__ counts, uint32_t* __restrict__ lists,
+                                                      uint32_t* __restrict__ pos_in_last /* may be null */) {
+  __shared__ uint32_t lcnt[8], lbase[8];
+  if (threadIdx.x < 8) lcnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = -1;
+  uint32_t rank = 0;
+  if (r < rows) {
+    const uint64_t k = (uint64_t)key[r];
+    if (k != 0) {
+      b = lim.nbins - 1;
+      for (int i = lim.nbins - 2; i >= 0; --i)
+        if (k <= lim.max[i]) b = i;
+      rank = atomicAdd(&lcnt[b], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < lim.nbins && lcnt[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&counts[threadIdx.x], lcnt[threadIdx.x]);
+  __syncthreads();
+  if (b >= 0) {
+    const uint32_t pos = lbase[b] + rank;
+    lists[(uint64_t)b * rows + pos] = r;
+    if (pos_in_last && b == lim.nbins - 1) pos_in_last[r] = pos;
+  }
+}
+
+// ---- linprobe in LDS --------------------------------------------------------------------------------
+// linprobe::HashSet::insert (set.rs:128-160) with the claim made atomic: returns true when the key is new.
+__device__ __forceinline__ bool lds_set_insert(uint32_t* table, uint32_t mask, uint32_t key) {
+  uint32_t h = (key * HASH_SCAL) & mask;
+  for (;;) {
+    const uint32_t old = atomicCAS(&table[h], EMPTY_KEY, key);
+    if (old == EMPTY_KEY) return true;
+    if (old == key) return false;
+    h = (h + 1) & mask;
+  }
+}
+// linprobe::HashMap::entry + and_modify/or_insert (map.rs:67-120; mul_hash.rs:157-161).  Values start at 0,
+// so "first product stored" and "+= product" are the same atomic add.
+template <class T>
+__device__ __forceinline__ void lds_map_upsert(uint32_t* keys, T* vals, uint32_t mask, uint32_t key, T v) {
+  uint32_t h = (key * HASH_SCAL) & mask;
+  for (;;) {
+    const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, key);
+    if (old == EMPTY_KEY || old == key) {
+      atomicAdd(&vals[h], v);
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+// ---- L4: symbolic, hash bins (mul_hash.rs:66-103) ----------------------------------------------------
+// G lanes cooperate on one row; sub-groups of S lanes each take one A entry k and stride over B's row k.
+template <int G, int S, int TABLE>
+__global__ __launch_bounds__((G > 256 ? G : 256)) void sym_hash_kernel(
+    const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const uint64_t* __restrict__ b_rp,
+    const uint32_t* __restrict__ b_col, const uint64_t* __restrict__ flops, const uint32_t* __restrict__ rows_list,
+    uint32_t nrows, uint32_t* __restrict__ row_nnz) {
+  constexpr int TPB = (G > 256 ? G : 256);
+  constexpr int RPW = TPB / G;
+  __shared__ uint32_t table[RPW][TABLE];
+  __shared__ uint32_t cnt[RPW];
+  const int g = threadIdx.x / G, gl = threadIdx.x % G;
+  const uint32_t ridx = blockIdx.x * RPW + g;
+  const bool valid = ridx < nrows;
+  const uint32_t row = valid ? rows_list[ridx] : 0;
+  uint32_t tsize = 0;
+  if (valid) {
+    const uint64_t f = flops[row];
+    tsize = table_size_for((uint32_t)(f > TABLE / 2 ? TABLE / 2 : f));  // hs.shrink_to(row_nz) (mul_hash.rs:87)
+    for (uint32_t i = gl; i < tsize; i += G) table[g][i] = EMPTY_KEY;
+  }
+  if (gl == 0) cnt[g] = 0;
+  __syncthreads();
+  if (valid) {
+    const uint32_t mask = tsize - 1;
+    const int sub = gl / S, sl = gl % S;
+    uint32_t mine = 0;
+    for (uint64_t p = a_rp[row] + sub, pe = a_rp[row + 1]; p < pe; p += G / S) {
+      const uint32_t k = a_col[p];
+      for (uint64_t q = b_rp[k] + sl, qe = b_rp[k + 1]; q < qe; q += S) mine += lds_set_insert(table[g], mask, b_col[q]);
+    }
+    if (mine) atomicAdd(&cnt[g], mine);
+  }
+  __syncthreads();
+  if (valid && gl == 0) row_nnz[row] = cnt[g];  // *row_nz = hs.len() (mul_hash.rs:95)
+}
+
+// ---- heavy rows: B rows pre-split at numeric-chunk boundaries ---------------------------------------
+// bpos[j * rows_b + k] = first position q in B's row k with col[q] >= j * CW, j = 0..nchunks (absolute, u32).
+__global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
+                                                  uint32_t rows_b, uint32_t nchunks, uint32_t* __restrict__ bpos) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t k = wave; k < rows_b; k += nwaves) {
+    const uint64_t s = b_rp[k], e = b_rp[k + 1];
+    for (uint64_t q = s + lane; q < e; q += 64) {
+      const uint32_t cq = b_col[q] >> CW_SHIFT;
+      const uint32_t cp = (q == s) ? 0u : (b_col[q - 1] >> CW_SHIFT);
+      for (uint32_t j = cp + 1; j <= cq; ++j) bpos[(uint64_t)j * rows_b + k] = (uint32_t)q;
+    }
+    if (lane == 0) {
+      bpos[k] = (uint32_t)s;
+      const uint32_t cl = (e > s) ? (b_col[e - 1] >> CW_SHIFT) : 0u;
+      for (uint32_t j = cl + 1; j <= nchunks; ++j) bpos[(uint64_t)j * rows_b + k] = (uint32_t)e;
+    }
+  }
+}
+
+// One workgroup per (heavy row, symbolic chunk): set a byte flag per produced column, then count per
+// numeric chunk.  No atomics on the flags: every writer stores the same value.
+template <bool USE_BPOS>
+__global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restrict__ a_rp,
+                                                        const uint32_t* __restrict__ a_col,
+                                                        const uint64_t* __restrict__ b_rp,
+                                                        const uint32_t* __restrict__ b_col,
+                                                        const uint32_t* __restrict__ bpos, uint32_t rows_b,
+                                                        const uint32_t* __restrict__ heavy_rows, uint32_t nsc,
+                                                        uint32_t nchunks, uint32_t* __restrict__ hcnt) {
+  __shared__ __attribute__((aligned(16))) uint8_t flags[SCW];
+  __shared__ uint32_t ccnt[SC_PER];
+  const uint32_t hrow = blockIdx.x / nsc, sc = blockIdx.x % nsc;
+  const uint32_t row = heavy_rows[hrow];
+  const uint32_t c0 = sc << SCW_SHIFT;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4* f4 = (u32x4*)flags;
+  for (int i = threadIdx.x; i < (int)(SCW / 16); i += 1024) f4[i] = (u32x4)(0u);
+  if (threadIdx.x < SC_PER) ccnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
+  // lanes per B row: wide when the A row is short (its B rows are then the long ones)
+  uint32_t S = 1024u / next_pow2_u32((uint32_t)std::min<uint64_t>(pe - ps, 1024));
+  S = S < 16 ? 16 : S;
+  const uint32_t sub = threadIdx.x / S, sl = threadIdx.x % S, nsub = 1024 / S;
+  const uint32_t j0 = sc * SC_PER, j1 = (j0 + SC_PER < nchunks) ? j0 + SC_PER : nchunks;
+  for (uint64_t p = ps + sub; p < pe; p += nsub) {
+    const uint32_t k = a_col[p];
+    if (USE_BPOS) {
+      const uint32_t lo = bpos[(uint64_t)j0 * rows_b + k], hi = bpos[(uint64_t)j1 * rows_b + k];
+      for (uint32_t q = lo + sl; q < hi; q += S) flags[b_col[q] - c0] = 1;
+    } else {
+      for (uint64_t q = b_rp[k] + sl, qe = b_rp[k + 1]; q < qe; q += S) {
+        const uint32_t c = b_col[q] - c0;
+        if (c < SCW) flags[c] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  // iteration i covers exactly numeric chunk j0 + i: 1024 threads x 16 flags = CW
+#pragma unroll
+  for (int i = 0; i < SC_PER; ++i) {
+    const u32x4 w = f4[i * 1024 + threadIdx.x];
+    uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+    n = wave_sum_u32(n);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&ccnt[i], n);
+  }
+  __syncthreads();
+  if (threadIdx.x < SC_PER && j0 + threadIdx.x < nchunks) hcnt[(uint64_t)hrow * nchunks + j0 + threadIdx.x] = ccnt[threadIdx.x];
+}
+
+// per heavy row: hoff = exclusive prefix of hcnt over chunks, row_nnz = total.  One wavefront per row.
+__global__ __launch_bounds__(256) void heavy_finalize_kernel(const uint32_t* __restrict__ heavy_rows, uint32_t n_heavy,
+                                                            uint32_t nchunks, const uint32_t* __restrict__ hcnt,
+                                                            uint32_t* __restrict__ hoff, uint32_t* __restrict__ row_nnz) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (h >= n_heavy) return;
+  uint32_t run = 0;
+  for (uint32_t base = 0; base < nchunks; base += 64) {
+    const uint32_t c = base + lane;
+    const uint32_t v = c < nchunks ? hcnt[(uint64_t)h * nchunks + c] : 0;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (c < nchunks) hoff[(uint64_t)h * nchunks + c] = run + inc - v;
+    run += __shfl(inc, 63, 64);
+  }
+  if (lane == 0) row_nnz[heavy_rows[h]] = run;
+}
+
+// list of non-empty (heavy row, chunk) items for the numeric pass
+__global__ __launch_bounds__(256) void heavy_items_kernel(const uint32_t* __restrict__ num_heavy_rows, uint32_t n_rows,
+                                                         const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks,
+                                                         const uint32_t* __restrict__ hcnt,
+                                                         unsigned long long* __restrict__ n_items,
+                                                         uint64_t* __restrict__ items) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)n_rows * nchunks) return;
+  const uint32_t r = num_heavy_rows[i / nchunks], c = (uint32_t)(i % nchunks);
+  const uint32_t h = hrow_of_row[r];
+  if (hcnt[(uint64_t)h * nchunks + c]) {
+    const unsigned long long pos = atomicAdd(n_items, 1ull);
+    items[pos] = ((uint64_t)h << 32) | c;
+  }
+}
+
+// ---- L5: numeric, hash bins (mul_hash.rs:106-201) ----------------------------------------------------
+template <class T, int G, int S, int TABLE>
+__global__ __launch_bounds__((G > 256 ? G : 256)) void num_hash_kernel(
+    const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
+    const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col, const T* __restrict__ b_val,
+    const uint32_t* __restrict__ rows_list, uint32_t nrows, const uint32_t* __restrict__ row_nnz,
+    const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ c_col, T* __restrict__ c_val) {
+  constexpr int TPB = (G > 256 ? G : 256);
+  constexpr int RPW = TPB / G;
+  __shared__ uint32_t keys[RPW][TABLE];
+  __shared__ T vals[RPW][TABLE];
+  __shared__ uint32_t wcnt[TPB / 64];
+  const int g = threadIdx.x / G, gl = threadIdx.x % G;
+  const uint32_t ridx = blockIdx.x * RPW + g;
+  const bool valid = ridx < nrows;
+  const uint32_t row = valid ? rows_list[ridx] : 0;
+  uint32_t tsize = 0;
+  if (valid) {
+    tsize = table_size_for(row_nnz[row]);  // hm.shrink_to(*row_nz) (mul_hash.rs:144)
+    for (uint32_t i = gl; i < tsize; i += G) {
+      keys[g][i] = EMPTY_KEY;
+      vals[g][i] = T(0);
+    }
+  }
+  __syncthreads();
+  if (valid) {
+    const uint32_t mask = tsize - 1;
+    const int sub = gl / S, sl = gl % S;
+    for (uint64_t p = a_rp[row] + sub, pe = a_rp[row + 1]; p < pe; p += G / S) {
+      const uint32_t k = a_col[p];
+      const T av = a_val[p];
+      for (uint64_t q = b_rp[k] + sl, qe = b_rp[k + 1]; q < qe; q += S)
+        lds_map_upsert<T>(keys[g], vals[g], mask, b_col[q], av * b_val[q]);  // t * t1 (mul_hash.rs:154)
+    }
+  }
+  __syncthreads();
+  // drain in slot order (map.rs:59-63): position = number of occupied slots before this one
+  const uint64_t out0 = valid ? c_rp[row] : 0;
+  if (G <= 64) {
+    if (valid) {
+      const int lane = threadIdx.x & 63;
+      const int gshift = lane & ~(G - 1);
+      const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+      uint32_t run = 0;
+      for (uint32_t base = 0; base < tsize; base += G) {
+        const uint32_t slot = base + gl;
+        const uint32_t key = keys[g][slot];
+        const bool occ = key != EMPTY_KEY;
+        const uint64_t m = (__ballot(occ) >> gshift) & gmask;
+        if (occ) {
+          const uint32_t pos = run + __popcll(m & ((1ull << gl) - 1));
+          c_col[out0 + pos] = key;
+          c_val[out0 + pos] = vals[g][slot];
+        }
+        run += __popcll(m);
+      }
+    }
+  } else {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t run = 0;
+    for (uint32_t base = 0; base < tsize; base += G) {  // one row per workgroup: uniform trip count
+      const uint32_t slot = base + gl;
+      const uint32_t key = slot < tsize ? keys[g][slot] : EMPTY_KEY;
+      const bool occ = key != EMPTY_KEY;
+      const uint64_t m = __ballot(occ);
+      if (lane == 0) wcnt[w] = __popcll(m);
+      __syncthreads();
+      uint32_t off = 0, tot = 0;
+#pragma unroll
+      for (int i = 0; i < TPB / 64; ++i) {
+        const uint32_t c = wcnt[i];
+        if (i < w) off += c;
+        tot += c;
+      }
+      if (occ) {
+        const uint32_t pos = run + off + __popcll(m & ((1ull << lane) - 1));
+        c_col[out0 + pos] = key;
+        c_val[out0 + pos] = vals[g][slot];
+      }
+      run += tot;
+      __syncthreads();
+    }
+  }
+}
+
+// One workgroup per non-empty (heavy row, numeric chunk): dense accumulator over CW columns in LDS.
+template <class T, bool USE_BPOS>
+__global__ __launch_bounds__(1024) void num_heavy_kernel(
+    const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
+    const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col, const T* __restrict__ b_val,
+    const uint32_t* __restrict__ bpos, uint32_t rows_b, const uint32_t* __restrict__ heavy_rows,
+    const uint64_t* __restrict__ items, uint32_t nchunks, const uint32_t* __restrict__ hoff,
+    const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ c_col, T* __restrict__ c_val) {
+  __shared__ __attribute__((aligned(16))) T acc[CW];
+  __shared__ __attribute__((aligned(16))) uint8_t flags[CW];
+  __shared__ uint32_t wcnt[16];
+  const uint64_t it = items[blockIdx.x];
+  const uint32_t hrow = (uint32_t)(it >> 32), chunk = (uint32_t)it;
+  const uint32_t row = heavy_rows[hrow];
+  const uint32_t c0 = chunk << CW_SHIFT;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4* f4 = (u32x4*)flags;
+  f4[threadIdx.x] = (u32x4)(0u);  // 1024 x 16 = CW flags
+  for (int i = threadIdx.x; i < (int)CW; i += 1024) acc[i] = T(0);
+  __syncthreads();
+  const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
+  uint32_t S = 1024u / next_pow2_u32((uint32_t)std::min<uint64_t>(pe - ps, 1024));
+  S = S < 16 ? 16 : S;
+  const uint32_t sub = threadIdx.x / S, sl = threadIdx.x % S, nsub = 1024 / S;
+  for (uint64_t p = ps + sub; p < pe; p += nsub) {
+    const uint32_t k = a_col[p];
+    const T av = a_val[p];
+    if (USE_BPOS) {
+      const uint32_t lo = bpos[(uint64_t)chunk * rows_b + k], hi = bpos[(uint64_t)(chunk + 1) * rows_b + k];
+      for (uint32_t q = lo + sl; q < hi; q += S) {
+        const uint32_t c = b_col[q] - c0;
+        atomicAdd(&acc[c], av * b_val[q]);
+        flags[c] = 1;
+      }
+    } else {
+      for (uint64_t q = b_rp[k] + sl, qe = b_rp[k + 1]; q < qe; q += S) {
+        const uint32_t c = b_col[q] - c0;
+        if (c < CW) {
+          atomicAdd(&acc[c], av * b_val[q]);
+          flags[c] = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // compaction in column order: thread t owns columns [16 t, 16 t + 16)
+  const u32x4 w = f4[threadIdx.x];
+  const uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t inc = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wcnt[wv] = inc;
+  __syncthreads();
+  uint32_t off = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < wv) off += wcnt[i];
+  uint64_t out = c_rp[row] + hoff[(uint64_t)hrow * nchunks + chunk] + off + inc - n;
+  if (n) {
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if ((ww[j >> 2] >> ((j & 3) * 8)) & 1u) {
+        const uint32_t c = threadIdx.x * 16 + j;
+        c_col[out] = c0 + c;
+        c_val[out] = acc[c];
+        ++out;
+      }
+    }
+  }
+}
+
+// ---- B2: sort each row by column (mul_hash.rs:164-175) ----------------------------------------------
+// Bitonic network over CAP LDS slots per row, padded with u32::MAX keys; G lanes per row.
+template <class T, int G, int CAP>
+__global__ __launch_bounds__((G > 256 ? G : 256)) void sort_rows_kernel(const uint32_t* __restrict__ rows_list,
+                                                                       uint32_t nrows,
+                                                                       const uint64_t* __restrict__ c_rp,
+                                                                       uint32_t* __restrict__ c_col,
+                                                                       T* __restrict__ c_val) {
+  constexpr int TPB = (G > 256 ? G : 256);
+  constexpr int RPW = TPB / G;
+  __shared__ uint32_t sk[RPW][CAP];
+  __shared__ T sv[RPW][CAP];
+  const int g = threadIdx.x / G, gl = threadIdx.x % G;
+  const uint32_t ridx = blockIdx.x * RPW + g;
+  const bool valid = ridx < nrows;
+  const uint32_t row = valid ? rows_list[ridx] : 0;
+  const uint64_t s = valid ? c_rp[row] : 0;
+  const uint32_t n = valid ? (uint32_t)(c_rp[row + 1] - s) : 0;
+  for (uint32_t i = gl; i < CAP; i += G) {
+    sk[g][i] = i < n ? c_col[s + i] : EMPTY_KEY;
+    sv[g][i] = i < n ? c_val[s + i] : T(0);
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= CAP; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = gl; i < CAP; i += G) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const uint32_t ki = sk[g][i], kl = sk[g][l];
+          const bool up = (i & k) == 0;
+          if ((ki > kl) == up) {
+            sk[g][i] = kl;
+            sk[g][l] = ki;
+            const T t = sv[g][i];
+            sv[g][i] = sv[g][l];
+            sv[g][l] = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = gl; i < n; i += G) {
+    c_col[s + i] = sk[g][i];
+    c_val[s + i] = sv[g][i];
+  }
+}
+
+}  // namespace spam
+
+// ---- plan ---------------------------------------------------------------------------------------------
+struct spam_spgemm_plan {
+  const spam_csr* a = nullptr;
+  const spam_csr* b = nullptr;
+  spam::DevBuf flops, row_nnz, c_row_ptr, scan_tmp;
+  spam::DevBuf heavy_rows;   // symbolic heavy list (copy of the last symbolic bin)
+  spam::DevBuf hrow_of_row;  // u32[rows]: index into heavy_rows
+  spam::DevBuf hcnt, hoff;   // u32[n_heavy * nchunks]
+  spam::DevBuf bpos;         // u32[(nchunks + 1) * rows_b]
+  uint32_t n_heavy = 0, nchunks = 0, nsc = 0;
+  bool use_bpos = false;
+  spam_spgemm_stats st{};
+  hipEvent_t ev[6] = {};
+  bool numeric_done = false;
+};
+
+namespace spam {
+
+static void plan_destroy(spam_spgemm_plan* p) {
+  if (!p) return;
+  for (auto& e : p->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete p;
+}
+
+static int launch_flops(const spam_csr* a, const spam_csr* b, uint64_t* d_flops, unsigned long long* d_total,
+                        hipStream_t s) {
+  SPAM_HIP_TRY(hipMemsetAsync(d_total, 0, 16, s));
+  unsigned grid = (unsigned)std::min<uint64_t>((a->rows + 3) / 4, 16384);
+  spgemm_flops_kernel<<<grid, 256, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, (uint32_t)a->rows, d_flops, d_total);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+static int check_pair(const spam_csr* a, const spam_csr* b) {
+  if (!a || !b) return set_error(SPAM_E_INVALID, "NULL matrix");
+  if (a->cols != b->rows)
+    return set_error(SPAM_E_INVALID,
+                     "LHS cols (%llu) != RHS rows (%llu): the reference would panic indexing rhs.offsets[k + 1] "
+                     "(mul_hash.rs:46)",
+                     (unsigned long long)a->cols, (unsigned long long)b->rows);
+  if (a->dtype != b->dtype) return set_error(SPAM_E_DTYPE, "A and B have different value types");
+  return SPAM_OK;
+}
+
+template <int G, int S, int TABLE>
+static int launch_sym_hash(const spam_csr* a, const spam_csr* b, const uint64_t* flops, const uint32_t* list,
+                           uint32_t n, uint32_t* row_nnz, hipStream_t s) {
+  if (!n) return SPAM_OK;
+  constexpr int TPB = (G > 256 ? G : 256);
+  constexpr int RPW = TPB / G;
+  sym_hash_kernel<G, S, TABLE><<<(n + RPW - 1) / RPW, TPB, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, flops,
+                                                                    list, n, row_nnz);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+template <class T, int G, int S, int TABLE>
+static int launch_num_hash(const spam_csr* a, const spam_csr* b, const uint32_t* list, uint32_t n,
+                           const uint32_t* row_nnz, const uint64_t* c_rp, uint32_t* c_col, T* c_val, hipStream_t s) {
+  if (!n) return SPAM_OK;
+  constexpr int TPB = (G > 256 ? G : 256);
+  constexpr int RPW = TPB / G;
+  num_hash_kernel<T, G, S, TABLE><<<(n + RPW - 1) / RPW, TPB, 0, s>>>(a->row_ptr, a->col_idx, (const T*)a->vals,
+                                                                       b->row_ptr, b->col_idx, (const T*)b->vals, list,
+                                                                       n, row_nnz, c_rp, c_col, c_val);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+template <class T, int G, int CAP>
+static int launch_sort(const uint32_t* list, uint32_t n, const uint64_t* c_rp, uint32_t* c_col, T* c_val,
+                       hipStream_t s) {
+  if (!n) return SPAM_OK;
+  constexpr int TPB = (G > 256 ? G : 256);
+  constexpr int RPW = TPB / G;
+  sort_rows_kernel<T, G, CAP><<<(n + RPW - 1) / RPW, TPB, 0, s>>>(list, n, c_rp, c_col, c_val);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan** plan_out, uint64_t* nnz_out) {
+  SPAM_TRY(check_pair(a, b));
+  hipStream_t s = stream();
+  spam_spgemm_plan* p = new (std::nothrow) spam_spgemm_plan();
+  if (!p) return set_error(SPAM_E_OOM, "host allocation failed");
+  struct Guard {
+    spam_spgemm_plan* p;
+    ~Guard() { plan_destroy(p); }
+  } guard{p};
+  p->a = a, p->b = b;
+  const uint32_t rows = (uint32_t)a->rows;
+  spam_spgemm_stats& st = p->st;
+  st.rows = a->rows, st.inner = a->cols, st.cols = b->cols, st.nnz_a = a->nnz, st.nnz_b = b->nnz;
+  for (auto& e : p->ev) SPAM_HIP_TRY(hipEventCreate(&e));
+  SPAM_HIP_TRY(hipEventRecord(p->ev[0], s));
+
+  // L1 flop count
+  DevBuf total;
+  SPAM_TRY(p->flops.alloc((uint64_t)rows * 8));
+  SPAM_TRY(total.alloc(16));
+  SPAM_TRY(launch_flops(a, b, p->flops.as<uint64_t>(), total.as<unsigned long long>(), s));
+  SPAM_HIP_TRY(hipEventRecord(p->ev[1], s));
+
+  // bin rows by F
+  DevBuf counts, lists;
+  SPAM_TRY(counts.alloc(8 * 4));
+  SPAM_TRY(lists.alloc((uint64_t)NSYM * rows * 4));
+  SPAM_TRY(p->hrow_of_row.alloc((uint64_t)rows * 4));
+  SPAM_TRY(p->row_nnz.alloc((uint64_t)rows * 4));
+  SPAM_HIP_TRY(hipMemsetAsync(counts.p, 0, 32, s));
+  SPAM_HIP_TRY(hipMemsetAsync(p->row_nnz.p, 0, (uint64_t)rows * 4, s));  // rows with F = 0 are skipped (mul_hash.rs:84)
+  BinLimits lim{};
+  lim.nbins = NSYM;
+  for (int i = 0; i < NSYM - 1; ++i) lim.max[i] = SYM_MAX[i];
+  bin_rows_kernel<uint64_t><<<(rows + 255) / 256, 256, 0, s>>>(p->flops.as<uint64_t>(), rows, lim, counts.as<uint32_t>(),
+                                                              lists.as<uint32_t>(), p->hrow_of_row.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  uint32_t hc[8];
+  unsigned long long htot[2];
+  SPAM_HIP_TRY(hipMemcpyAsync(hc, counts.p, 32, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(htot, total.p, 16, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  if (htot[1]) return set_error(SPAM_E_OVERFLOW, "intermediate-product count overflows usize (mul_hash.rs:47-48)");
+  st.flops_f = htot[0];
+  for (int i = 0; i < NSYM; ++i) st.rows_sym_bin[i] = hc[i];
+
+  const uint32_t* L = lists.as<uint32_t>();
+  uint32_t* rn = p->row_nnz.as<uint32_t>();
+  const uint64_t* fl = p->flops.as<uint64_t>();
+  SPAM_TRY((launch_sym_hash<16, 4, 128>(a, b, fl, L + 0ull * rows, hc[0], rn, s)));
+  SPAM_TRY((launch_sym_hash<64, 8, 1024>(a, b, fl, L + 1ull * rows, hc[1], rn, s)));
+  SPAM_TRY((launch_sym_hash<256, 16, 8192>(a, b, fl, L + 2ull * rows, hc[2], rn, s)));
+
+  // heavy rows: dense flags per symbolic chunk
+  p->n_heavy = hc[NSYM - 1];
+  p->nchunks = (uint32_t)((b->cols + CW - 1) >> CW_SHIFT);
+  p->nsc = (uint32_t)((b->cols + SCW - 1) >> SCW_SHIFT);
+  if (p->n_heavy) {
+    if ((uint64_t)p->n_heavy * p->nsc >= (1ull << 31))
+      return set_error(SPAM_E_UNSUPPORTED, "too many heavy (row, chunk) items for one launch");
+    SPAM_TRY(p->heavy_rows.alloc((uint64_t)p->n_heavy * 4));
+    SPAM_HIP_TRY(hipMemcpyAsync(p->heavy_rows.p, L + (uint64_t)(NSYM - 1) * rows, (uint64_t)p->n_heavy * 4,
+                                hipMemcpyDeviceToDevice, s));
+    p->use_bpos = b->is_sorted && p->nchunks > 1 && b->nnz < (1ull << 32);
+    if (p->use_bpos) {
+      SPAM_TRY(p->bpos.alloc((uint64_t)(p->nchunks + 1) * b->rows * 4));
+      unsigned grid = (unsigned)std::min<uint64_t>((b->rows + 3) / 4, 16384);
+      bpos_kernel<<<grid, 256, 0, s>>>(b->row_ptr, b->col_idx, (uint32_t)b->rows, p->nchunks, p->bpos.as<uint32_t>());
+      SPAM_CHECK_LAUNCH();
+    }
+    SPAM_TRY(p->hcnt.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
+    SPAM_TRY(p->hoff.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
+    const unsigned grid = p->n_heavy * p->nsc;
+    if (p->use_bpos)
+      sym_heavy_kernel<true><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, p->bpos.as<uint32_t>(),
+                                                   (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->nsc, p->nchunks,
+                                                   p->hcnt.as<uint32_t>());
+    else
+      sym_heavy_kernel<false><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, nullptr,
+                                                    (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->nsc, p->nchunks,
+                                                    p->hcnt.as<uint32_t>());
+    SPAM_CHECK_LAUNCH();
+    heavy_finalize_kernel<<<(p->n_heavy + 3) / 4, 256, 0, s>>>(p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
+                                                              p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn);
+    SPAM_CHECK_LAUNCH();
+  }
+
+  // offsets = checked_inclusive_scan(row_nz) (mul_hash.rs:117)
+  SPAM_TRY(p->c_row_ptr.alloc(((uint64_t)rows + 1) * 8));
+  SPAM_TRY(p->scan_tmp.alloc(scan_tmp_bytes(rows)));
+  SPAM_TRY(scan_u32_to_u64(rn, rows, p->c_row_ptr.as<uint64_t>(), p->scan_tmp.p, s));
+  SPAM_HIP_TRY(hipEventRecord(p->ev[2], s));
+  uint64_t nnz_c = 0;
+  SPAM_HIP_TRY(hipMemcpyAsync(&nnz_c, p->c_row_ptr.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  st.nnz_c = nnz_c;
+  (void)hipEventElapsedTime(&st.ms_flops, p->ev[0], p->ev[1]);
+  (void)hipEventElapsedTime(&st.ms_symbolic, p->ev[1], p->ev[2]);
+  if (nnz_out) *nnz_out = nnz_c;
+  guard.p = nullptr;
+  *plan_out = p;
+  return SPAM_OK;
+}
+
+template <class T>
+static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
+  const spam_csr *a = p->a, *b = p->b;
+  hipStream_t s = stream();
+  const uint32_t rows = (uint32_t)a->rows;
+  spam_spgemm_stats& st = p->st;
+  SPAM_HIP_TRY(hipEventRecord(p->ev[3], s));
+  DevBuf ccol, cval;
+  SPAM_TRY(ccol.alloc(st.nnz_c * 4));
+  SPAM_TRY(cval.alloc(st.nnz_c * sizeof(T)));
+  SPAM_HIP_TRY(hipEventRecord(p->ev[4], s));
+
+  DevBuf counts, lists;
+  SPAM_TRY(counts.alloc(8 * 4 + 8));
+  SPAM_TRY(lists.alloc((uint64_t)NNUM * rows * 4));
+  SPAM_HIP_TRY(hipMemsetAsync(counts.p, 0, 40, s));
+  BinLimits lim{};
+  lim.nbins = NNUM;
+  for (int i = 0; i < NNUM - 1; ++i) lim.max[i] = NUM_MAX[i];
+  bin_rows_kernel<uint32_t><<<(rows + 255) / 256, 256, 0, s>>>(p->row_nnz.as<uint32_t>(), rows, lim, counts.as<uint32_t>(),
+                                                              lists.as<uint32_t>(), nullptr);
+  SPAM_CHECK_LAUNCH();
+  uint32_t hc[8];
+  SPAM_HIP_TRY(hipMemcpyAsync(hc, counts.p, 32, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < NNUM; ++i) st.rows_num_bin[i] = hc[i];
+
+  const uint32_t* L = lists.as<uint32_t>();
+  const uint32_t* rn = p->row_nnz.as<uint32_t>();
+  const uint64_t* crp = p->c_row_ptr.as<uint64_t>();
+  uint32_t* cc = ccol.as<uint32_t>();
+  T* cv = cval.as<T>();
+  SPAM_TRY((launch_num_hash<T, 16, 4, 128>(a, b, L + 0ull * rows, hc[0], rn, crp, cc, cv, s)));
+  SPAM_TRY((launch_num_hash<T, 64, 8, 1024>(a, b, L + 1ull * rows, hc[1], rn, crp, cc, cv, s)));
+  SPAM_TRY((launch_num_hash<T, 256, 16, 4096>(a, b, L + 2ull * rows, hc[2], rn, crp, cc, cv, s)));
+  SPAM_TRY((launch_num_hash<T, 1024, 16, 8192>(a, b, L + 3ull * rows, hc[3], rn, crp, cc, cv, s)));
+
+  const uint32_t n_hnum = hc[NNUM - 1];
+  if (n_hnum) {
+    // non-empty (row, chunk) items
+    const uint64_t cand = (uint64_t)n_hnum * p->nchunks;
+    DevBuf items;
+    SPAM_TRY(items.alloc(cand * 8));
+    unsigned long long* d_nitems = (unsigned long long*)(counts.as<uint32_t>() + 8);
+    heavy_items_kernel<<<(unsigned)((cand + 255) / 256), 256, 0, s>>>(L + (uint64_t)(NNUM - 1) * rows, n_hnum,
+                                                                       p->hrow_of_row.as<uint32_t>(), p->nchunks,
+                                                                       p->hcnt.as<uint32_t>(), d_nitems,
+                                                                       items.as<uint64_t>());
+    SPAM_CHECK_LAUNCH();
+    unsigned long long n_items = 0;
+    SPAM_HIP_TRY(hipMemcpyAsync(&n_items, d_nitems, 8, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+    st.heavy_items = n_items;
+    if (n_items >= (1ull << 31)) return set_error(SPAM_E_UNSUPPORTED, "too many heavy (row, chunk) items for one launch");
+    if (n_items) {
+      if (p->use_bpos)
+        num_heavy_kernel<T, true><<<(unsigned)n_items, 1024, 0, s>>>(
+            a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals, p->bpos.as<uint32_t>(),
+            (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), items.as<uint64_t>(), p->nchunks, p->hoff.as<uint32_t>(),
+            crp, cc, cv);
+      else
+        num_heavy_kernel<T, false><<<(unsigned)n_items, 1024, 0, s>>>(
+            a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals, nullptr,
+            (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), items.as<uint64_t>(), p->nchunks, p->hoff.as<uint32_t>(),
+            crp, cc, cv);
+      SPAM_CHECK_LAUNCH();
+    }
+    SPAM_HIP_TRY(hipStreamSynchronize(s));  // items is freed at scope exit
+  }
+  if (sort_rows) {
+    SPAM_TRY((launch_sort<T, 16, 64>(L + 0ull * rows, hc[0], crp, cc, cv, s)));
+    SPAM_TRY((launch_sort<T, 64, 512>(L + 1ull * rows, hc[1], crp, cc, cv, s)));
+    SPAM_TRY((launch_sort<T, 256, 2048>(L + 2ull * rows, hc[2], crp, cc, cv, s)));
+    SPAM_TRY((launch_sort<T, 1024, 4096>(L + 3ull * rows, hc[3], crp, cc, cv, s)));
+  }
+  SPAM_HIP_TRY(hipEventRecord(p->ev[5], s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  (void)hipEventElapsedTime(&st.ms_alloc, p->ev[3], p->ev[4]);
+  (void)hipEventElapsedTime(&st.ms_numeric, p->ev[4], p->ev[5]);
+  st.ms_total = st.ms_flops + st.ms_symbolic + st.ms_alloc + st.ms_numeric;
+
+  spam_csr* c = new (std::nothrow) spam_csr();
+  if (!c) return set_error(SPAM_E_OOM, "host allocation failed");
+  c->rows = a->rows, c->cols = b->cols, c->nnz = st.nnz_c, c->dtype = a->dtype;
+  // heavy rows are always sorted; hash rows only when asked (the const generic B2)
+  c->is_sorted = sort_rows ? 1 : 0;
+  c->row_ptr = (uint64_t*)p->c_row_ptr.release();
+  c->col_idx = (uint32_t*)ccol.release();
+  c->vals = cval.release();
+  c->owns_row_ptr = c->owns_col_val = true;
+  if (c->nnz < (1ull << 32)) {
+    DevBuf r32;
+    if (int e = r32.alloc((c->rows + 1) * 4)) {
+      spam_csr_free(c);
+      return e;
+    }
+    c->row_ptr32 = (uint32_t*)r32.release();
+    c->owns_row_ptr32 = true;
+    if (int e = narrow_row_ptr(c->row_ptr, c->rows + 1, c->row_ptr32, s)) {
+      spam_csr_free(c);
+      return e;
+    }
+  }
+  p->numeric_done = true;
+  *c_out = c;
+  return SPAM_OK;
+}
+
+static int numeric_dev_impl(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
+  if (!p || !c_out) return set_error(SPAM_E_INVALID, "NULL argument");
+  *c_out = nullptr;
+  if (p->numeric_done) return set_error(SPAM_E_INVALID, "plan already consumed by a numeric call");
+  return p->a->dtype == SPAM_F64 ? numeric_typed<double>(p, sort_rows, c_out) : numeric_typed<float>(p, sort_rows, c_out);
+}
+
+}  // namespace spam
+
+using namespace spam;
+
+extern "C" {
+
+int spam_spgemm_symbolic(const spam_csr* a, const spam_csr* b, spam_spgemm_plan** plan, uint64_t* nnz_out) {
+  clear_error();
+  if (!plan) return set_error(SPAM_E_INVALID, "plan is NULL");
+  *plan = nullptr;
+  return symbolic_impl(a, b, plan, nnz_out);
+}
+
+int spam_spgemm_numeric_dev(spam_spgemm_plan* plan, int sort_rows, spam_csr** c_out) {
+  clear_error();
+  return numeric_dev_impl(plan, sort_rows, c_out);
+}
+
+int spam_spgemm_numeric_f64(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out, uint64_t* indices_out,
+                            double* vals_out) {
+  clear_error();
+  if (plan && plan->a->dtype != SPAM_F64) return set_error(SPAM_E_DTYPE, "plan holds f32 matrices");
+  spam_csr* c = nullptr;
+  SPAM_TRY(numeric_dev_impl(plan, sort_rows, &c));
+  int e = spam_csr_download_f64(c, offsets_out, indices_out, vals_out);
+  spam_csr_free(c);
+  return e;
+}
+
+int spam_spgemm_numeric_f32(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out, uint64_t* indices_out,
+                            float* vals_out) {
+  clear_error();
+  if (plan && plan->a->dtype != SPAM_F32) return set_error(SPAM_E_DTYPE, "plan holds f64 matrices");
+  spam_csr* c = nullptr;
+  SPAM_TRY(numeric_dev_impl(plan, sort_rows, &c));
+  int e = spam_csr_download_f32(c, offsets_out, indices_out, vals_out);
+  spam_csr_free(c);
+  return e;
+}
+
+int spam_spgemm_plan_stats(const spam_spgemm_plan* plan, spam_spgemm_stats* stats) {
+  clear_error();
+  if (!plan || !stats) return set_error(SPAM_E_INVALID, "NULL argument");
+  *stats = plan->st;
+  return SPAM_OK;
+}
+
+void spam_spgemm_plan_free(spam_spgemm_plan* plan) { plan_destroy(plan); }
+
+int spam_spgemm_dev(const spam_csr* a, const spam_csr* b, int sort_rows, spam_csr** c_out, spam_spgemm_stats* stats) {
+  clear_error();
+  if (!c_out) return set_error(SPAM_E_INVALID, "c_out is NULL");
+  *c_out = nullptr;
+  spam_spgemm_plan* p = nullptr;
+  uint64_t nnz = 0;
+  SPAM_TRY(symbolic_impl(a, b, &p, &nnz));
+  int e = numeric_dev_impl(p, sort_rows, c_out);
+  if (stats) *stats = p->st;
+  plan_destroy(p);
+  return e;
+}
+
+int spam_rows_to_parts(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t* row_flops_out,
+                       uint64_t* rows_offset_out) {
+  clear_error();
+  if (!rows_offset_out || nparts == 0) return set_error(SPAM_E_INVALID, "bad nparts / NULL output");
+  SPAM_TRY(check_pair(a, b));
+  hipStream_t s = stream();
+  DevBuf flops, total;
+  SPAM_TRY(flops.alloc(a->rows * 8));
+  SPAM_TRY(total.alloc(16));
+  SPAM_TRY(launch_flops(a, b, flops.as<uint64_t>(), total.as<unsigned long long>(), s));
+  std::vector<uint64_t> f(a->rows);
+  unsigned long long htot[2];
+  SPAM_HIP_TRY(hipMemcpyAsync(f.data(), flops.p, a->rows * 8, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(htot, total.p, 16, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  if (htot[1]) return set_error(SPAM_E_OVERFLOW, "intermediate-product count overflows usize (mul_hash.rs:47-48)");
+  if (row_flops_out) std::copy(f.begin(), f.end(), row_flops_out);
+  // mul_hash.rs:51-62: prefix sum, average = ceil(total / tnum), partition_point(ps, x <= average * tid) - 1
+  std::vector<uint64_t> ps(a->rows + 1);
+  ps[0] = 0;
+  for (uint64_t i = 0; i < a->rows; ++i) ps[i + 1] = ps[i] + f[i];
+  const uint64_t tot = ps.back();
+  const uint64_t avg = tot / nparts + (tot % nparts != 0);
+  rows_offset_out[0] = 0;
+  for (uint64_t t = 1; t < nparts; ++t) {
+    const uint64_t bound = avg * t;
+    uint64_t pp = (uint64_t)(std::partition_point(ps.begin(), ps.end(), [&](uint64_t x) { return x <= bound; }) - ps.begin());
+    rows_offset_out[t] = pp - 1;
+  }
+  rows_offset_out[nparts] = a->rows;
+  return SPAM_OK;
+}
+
+}  // extern "C"

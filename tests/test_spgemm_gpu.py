@@ -1,0 +1,172 @@
+"""SpGEMM parity on the MI355X: libspam_hip.so (through the C ABI) against the CPU oracle of
+CsrMatrix::mul_hash (spam_csr/src/mul_hash.rs:13-201).
+
+Bar (BASELINE.json north_star): row_ptr bit-exact; col_idx bit-exact with sort_rows (B2 = true) and
+per-row set-equal without (the reference's own test compares order-insensitively through DokMatrix,
+spam_csr/src/tests.rs:356-371); f64 values within 1e-10 relative on positive data, Higham's bound
+(spam_dok/src/lib.rs:56-92) on signed data.
+"""
+import numpy as np
+import pytest
+import torch
+
+from sparse_matrix_amd import synth
+from helpers import assert_csr_parity, csr_np, rows_as_sets
+
+pytestmark = pytest.mark.gpu
+
+F64_RTOL = 1e-10
+F32_RTOL = 2e-5
+
+
+def _mk(spam, m, is_sorted=True):
+    off, idx, val = csr_np(m)
+    return spam.CsrMatrix(m.rows, m.cols, val, idx, off, is_sorted), (off, idx, val)
+
+
+def _both(spam, oracle, ma, mb, rtol, a_sorted=True, b_sorted=True):
+    A, a = _mk(spam, ma, a_sorted)
+    B, b = _mk(spam, mb, b_sorted)
+    for sort_rows in (True, False):
+        C = A.mul_hash(B, sort_output=sort_rows)
+        want = oracle.mul_hash(a, b, sort_rows=sort_rows)
+        assert C.rows() == ma.rows and C.cols() == mb.cols
+        assert C.invariants()
+        assert_csr_parity((C.offsets, C.indices, C.vals), want, sort_rows, rtol)
+    return C
+
+
+def test_banded_cfg1(spam, oracle):
+    """BASELINE configs[0]: 10k x 10k banded, C = A*A: F = 249 950, nnz(C) = 89 980."""
+    m = synth.banded(10000, 5)
+    C = _both(spam, oracle, m, m, F64_RTOL)
+    assert C.nnz() == 89980
+
+
+@pytest.mark.parametrize("scale", [6, 10, 13])
+def test_rmat_square(spam, oracle, scale):
+    """R-MAT A*A: scale 13 has rows in every bin incl. the dense-chunk path (nnz(C_i) > 4096)."""
+    m = synth.rmat(scale)
+    _both(spam, oracle, m, m, F64_RTOL)
+
+
+def test_rmat_multi_chunk(spam, oracle):
+    """scale 16: 65 536 columns = 4 numeric chunks; heavy rows use B pre-split at chunk boundaries."""
+    m = synth.rmat(16)
+    A, a = _mk(spam, m)
+    dev = A.device()
+    C, st = dev.spgemm(dev, sort_rows=True)
+    got = C.download()
+    want = oracle.mul_hash(a, a, sort_rows=True)
+    assert st["rows_num_bin"][4] > 0 and st["heavy_items"] > 0
+    assert st["flops_f"] == int(oracle.rows_to_threads(a[0], a[1], a[0], 1)[0].sum())
+    assert_csr_parity(got, want, True, F64_RTOL)
+    assert C.invariants()
+
+
+def test_wide_b_many_symbolic_chunks(spam, oracle):
+    """B with 300 000 columns: 3 symbolic chunks of 131 072 and 19 numeric chunks per heavy row."""
+    ma = synth.random_csr(16, 500, 0.5, seed=11, signed=False)
+    mb = synth.random_csr(500, 300_000, 0.002, seed=12, signed=False)
+    _both(spam, oracle, ma, mb, F64_RTOL)
+
+
+def test_unsorted_b_heavy_rows_filter_path(spam, oracle):
+    """Unsorted B cannot be pre-split; heavy rows then filter every product by chunk."""
+    ma = synth.random_csr(8, 300, 0.6, seed=21, signed=False)
+    mb = synth.random_csr(300, 40_000, 0.05, seed=22, signed=False, sort_rows=False)
+    _both(spam, oracle, ma, mb, F64_RTOL, b_sorted=False)
+
+
+def test_f32(spam, oracle):
+    m = synth.rmat(11, dtype=torch.float32)
+    _both(spam, oracle, m, m, F32_RTOL)
+
+
+def test_rectangular_and_empty_rows(spam, oracle):
+    ma = synth.random_csr(300, 200, 0.02, seed=1, signed=False)
+    mb = synth.random_csr(200, 450, 0.03, seed=2, signed=False)
+    _both(spam, oracle, ma, mb, F64_RTOL)
+
+
+def test_identity_is_neutral(spam):
+    """I*A = A*I = A as (row, col) -> value maps (SURVEY.md §8c algebraic KAT)."""
+    m = synth.rmat(9)
+    A, a = _mk(spam, m)
+    I = spam.CsrMatrix.identity(m.rows)
+    for C in (I.mul_hash(A, True), A.mul_hash(I, True)):
+        assert np.array_equal(C.offsets, a[0]) and np.array_equal(C.indices, a[1]) and np.array_equal(C.vals, a[2])
+
+
+def test_cancellation_keeps_explicit_zero(spam):
+    """a*b + (-a*b): mul_hash keeps the structural entry with value 0.0 (structure = symbolic pattern);
+    it disappears only in the CSR -> DOK conversion (spam_dok/src/lib.rs:171-175)."""
+    A = spam.CsrMatrix.from_dok((1, 2), {(0, 0): 2.0, (0, 1): -2.0})
+    B = spam.CsrMatrix.from_dok((2, 2), {(0, 0): 3.0, (1, 0): 3.0, (1, 1): 1.0})
+    C = A.mul_hash(B, sort_output=True)
+    assert C.indices.tolist() == [0, 1] and C.vals.tolist() == [0.0, -2.0]
+    assert C.to_dok() == {(0, 1): -2.0}
+
+
+def test_property_small_random_vs_dok(spam, oracle):
+    """The reference's hot-path test (spam_csr/src/tests.rs:356-371) and fuzz property
+    (fuzz/fuzz_targets/mul_hash.rs:28-46) on the GPU path: unsorted CSR inputs from DOK matrices of
+    dimension 1..4 (and up to 40), mul_hash::<false,false>, invariants hold, CSR -> DOK equals the DOK
+    triple loop within Higham's bound."""
+    from oracle import dok
+
+    rng = np.random.default_rng(1234)
+    for case in range(120):
+        big = case % 4 == 3
+        l, m, n = (rng.integers(1, 41, 3) if big else rng.integers(1, 5, 3))
+        da = {(int(rng.integers(l)), int(rng.integers(m))): float(rng.normal()) for _ in range(int(rng.integers(0, 2 * l * m + 1)))}
+        db = {(int(rng.integers(m)), int(rng.integers(n))): float(rng.normal()) for _ in range(int(rng.integers(0, 2 * m * n + 1)))}
+        A = spam.CsrMatrix.from_dok((l, m), da, rng=rng)
+        B = spam.CsrMatrix.from_dok((m, n), db, rng=rng)
+        C = A.mul_hash(B, sort_output=False)
+        assert C.invariants()
+        ad = dok.to_dense(l, m, A.offsets, A.indices, A.vals)
+        bd = dok.to_dense(m, n, B.offsets, B.indices, B.vals)
+        cd = dok.to_dense(l, n, C.offsets, C.indices, C.vals)
+        assert dok.is_good_approx_of_mul(cd, ad, bd)
+        # structure: exactly the symbolic pattern of the oracle
+        want = oracle.mul_hash((A.offsets, A.indices, A.vals), (B.offsets, B.indices, B.vals), sort_rows=False)
+        assert np.array_equal(C.offsets, want[0])
+        assert rows_as_sets(C.offsets, C.indices) == rows_as_sets(want[0], want[1])
+
+
+def test_dimension_mismatch_is_an_error(spam):
+    """The reference panics on rhs.offsets[k + 1] (mul_hash.rs:46); the ABI reports SPAM_E_INVALID."""
+    A = spam.CsrMatrix.identity(4)
+    B = spam.CsrMatrix.identity(5)
+    with pytest.raises(spam.SpamError) as e:
+        A.mul_hash(B)
+    assert e.value.code == 1
+
+
+def test_rows_to_parts_matches_oracle(spam, oracle):
+    """rows_to_threads with tnum = #GPUs (mul_hash.rs:38-64) + its own post-conditions (:204-224)."""
+    m = synth.rmat(12)
+    A, a = _mk(spam, m)
+    for parts in (1, 2, 3, 8):
+        flops, offs = A.device().rows_to_parts(A.device(), parts)
+        rn, ro = oracle.rows_to_threads(a[0], a[1], a[0], parts)
+        assert np.array_equal(flops, rn) and np.array_equal(offs, ro)
+        assert np.all(np.diff(offs.astype(np.int64)) >= 0) and offs[-1] == m.rows
+
+
+def test_row_block_product_equals_slice(spam, oracle):
+    """C[lo:hi, :] = A[lo:hi, :] * B — what each GPU computes in the row-sharded multi-GPU run."""
+    m = synth.rmat(11)
+    A, a = _mk(spam, m)
+    dev = A.device()
+    want = oracle.mul_hash(a, a, sort_rows=True)
+    _, offs = dev.rows_to_parts(dev, 3)
+    for lo, hi in zip(offs[:-1].tolist(), offs[1:].tolist()):
+        if hi == lo:
+            continue
+        C, _ = dev.row_block(lo, hi).spgemm(dev, sort_rows=True)
+        o, i, v = C.download()
+        wo = want[0][lo:hi + 1] - want[0][lo]
+        s, e = int(want[0][lo]), int(want[0][hi])
+        assert_csr_parity((o, i, v), (wo, want[1][s:e], want[2][s:e]), True, F64_RTOL)

@@ -1,0 +1,124 @@
+"""SpMV parity on the MI355X: libspam_hip.so (through the C ABI) against the CPU oracle.
+
+The reference has no SpMV; the oracle's definition is mul_hash with an n x 1 right-hand side
+(SURVEY.md §3.5).  Tolerance: 1e-10 relative for f64 (BASELINE.json north_star), 1e-5 for f32 against
+the f64-accumulated oracle; inputs are positive so relative error is meaningful.
+"""
+import numpy as np
+import pytest
+import torch
+
+from sparse_matrix_amd import synth
+from helpers import csr_np
+
+pytestmark = pytest.mark.gpu
+
+F64_RTOL = 1e-10
+F32_RTOL = 1e-5
+
+
+def _check(spam, oracle, m, rtol, is_sorted=True):
+    off, idx, val = csr_np(m)
+    x = synth.dense_vector(m.cols, dtype=m.vals.dtype).numpy()
+    A = spam.CsrMatrix(m.rows, m.cols, val, idx, off, is_sorted)
+    y = A.spmv(x)
+    if val.dtype == np.float32:
+        ref = oracle.spmv((off, idx, val.astype(np.float64)), x.astype(np.float64))
+    else:
+        ref = oracle.spmv((off, idx, val), x)
+    assert y.shape == ref.shape
+    nz = ref != 0
+    assert np.array_equal(y[~nz], ref[~nz].astype(y.dtype)), "rows without entries must give exactly 0"
+    rel = np.abs(y[nz].astype(np.float64) - ref[nz]) / np.abs(ref[nz])
+    assert rel.size == 0 or rel.max() <= rtol, f"max rel err {rel.max():.3e}"
+    return y, ref
+
+
+def test_banded_cfg1(spam, oracle):
+    """BASELINE configs[0]: 10k x 10k banded bw=5.  A row that lies inside one nnz tile is summed by one
+    lane left to right — the oracle's order — so it is bit-identical; only rows cut by a tile boundary
+    (every 2048 / 4096 entries) are summed as partial + partial and may differ in the last bit."""
+    m = synth.banded(10000, 5)
+    y, ref = _check(spam, oracle, m, F64_RTOL)
+    off = m.row_ptr.numpy()
+    inside = (off[:-1] // 2048) == ((off[1:] - 1) // 2048)
+    assert inside.sum() > 9900
+    assert np.array_equal(y[inside], ref[inside])
+
+
+@pytest.mark.parametrize("scale", [8, 12, 16])
+def test_rmat_f64(spam, oracle, scale):
+    _check(spam, oracle, synth.rmat(scale), F64_RTOL)
+
+
+def test_rmat_rect_f64(spam, oracle):
+    """Non power-of-two clip of R-MAT (the cfg2 generator) at 300k rows."""
+    _check(spam, oracle, synth.rmat_rect(300_000, 4_800_000), F64_RTOL)
+
+
+def test_powerlaw_f32_long_rows(spam, oracle):
+    """cfg5 shape at 1/50 scale: rows of 50 000 entries span a dozen tiles (carry path) next to rows of 8."""
+    _check(spam, oracle, synth.powerlaw(40_000, heavy_every=1000, heavy_nnz=30_000, light_nnz=8, dtype=torch.float32), F32_RTOL)
+
+
+def test_powerlaw_f64_long_rows(spam, oracle):
+    _check(spam, oracle, synth.powerlaw(60_000, heavy_every=500, heavy_nnz=50_000, light_nnz=8,
+                                        dtype=torch.float64), F64_RTOL)
+
+
+def test_single_dense_row_and_empty_rows(spam, oracle):
+    """One row holding every entry, all other rows empty; plus trailing empty rows at a tile boundary."""
+    n = 9000
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[5:] = n  # row 4 has n entries
+    idx = np.arange(n, dtype=np.uint64)
+    val = np.linspace(0.5, 1.5, n)
+    A = spam.CsrMatrix(n, n, val, idx, off, True)
+    x = synth.dense_vector(n).numpy()
+    y = A.spmv(x)
+    ref = oracle.spmv((off, idx, val), x)
+    assert np.all(y[np.arange(n) != 4] == 0)
+    assert abs(y[4] - ref[4]) <= F64_RTOL * abs(ref[4])
+
+
+def test_rows_exactly_on_tile_boundaries(spam, oracle):
+    """Rows of 4096 entries: every row starts exactly where a 4096-entry tile starts (and 2048 for NPT=8)."""
+    rows, cols, L = 6, 5000, 4096
+    off = (np.arange(rows + 1) * L).astype(np.uint64)
+    idx = np.tile(np.arange(L, dtype=np.uint64), rows)
+    val = 0.5 + np.random.default_rng(0).random(rows * L)
+    A = spam.CsrMatrix(rows, cols, val, idx, off, True)
+    x = synth.dense_vector(cols).numpy()
+    y = A.spmv(x)
+    ref = oracle.spmv((off, idx, val), x)
+    assert np.abs(y - ref).max() <= F64_RTOL * np.abs(ref).max()
+
+
+def test_empty_matrix(spam):
+    A = spam.CsrMatrix.new((7, 3))
+    assert np.array_equal(A.spmv(np.ones(3)), np.zeros(7))
+
+
+def test_unsorted_rows(spam, oracle):
+    _check(spam, oracle, synth.random_csr(500, 700, 0.05, seed=3, signed=False, sort_rows=False), F64_RTOL,
+           is_sorted=False)
+
+
+def test_row_block_view(spam, oracle):
+    """A row block of A (what each GPU holds) gives the matching slice of y."""
+    m = synth.rmat(12)
+    off, idx, val = csr_np(m)
+    A = spam.CsrMatrix(m.rows, m.cols, val, idx, off, True)
+    x = synth.dense_vector(m.cols).numpy()
+    ref = oracle.spmv((off, idx, val), x)
+    lo, hi = 1000, 3001
+    blk = A.device().row_block(lo, hi)
+    y = blk.spmv(x)
+    assert blk.invariants()
+    assert np.abs(y - ref[lo:hi]).max() <= F64_RTOL * np.abs(ref).max()
+
+
+def test_wrong_x_length_is_an_error(spam):
+    A = spam.CsrMatrix.identity(4)
+    with pytest.raises(spam.SpamError):
+        A.spmv(np.ones(5))
