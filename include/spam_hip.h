@@ -64,6 +64,9 @@ int spam_hip_init(int device);
 int spam_hip_set_stream(void* hip_stream);
 /* Block until everything queued on the library stream has finished. */
 int spam_hip_synchronize(void);
+/* The library keeps freed device blocks for reuse (a 100 GB C costs seconds of hipMalloc otherwise);
+ * this hands all cached blocks back to the driver. */
+int spam_hip_trim(void);
 /* Message of the last failing call on this thread ("" if none).  Never NULL. */
 const char* spam_last_error(void);
 /* Library/ABI version: major*1000 + minor. */

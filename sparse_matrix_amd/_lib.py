@@ -50,6 +50,7 @@ SYMBOLS = {
     "spam_hip_init": (C.c_int, [C.c_int]),
     "spam_hip_set_stream": (C.c_int, [_P]),
     "spam_hip_synchronize": (C.c_int, []),
+    "spam_hip_trim": (C.c_int, []),
     "spam_last_error": (C.c_char_p, []),
     "spam_version": (C.c_int, []),
     "spam_csr_upload_f64": (C.c_int, [_U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),

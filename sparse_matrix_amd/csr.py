@@ -99,6 +99,13 @@ class DeviceCsr:
         check(fn(self._h, _vp(offsets), _vp(indices), _vp(vals)))
         return offsets, indices, vals
 
+    def download_row_ptr(self) -> np.ndarray:
+        rows, _, _, dt, _ = self.dims()
+        offsets = np.empty(rows + 1, dtype=np.uint64)
+        fn = _lib.load().spam_csr_download_f64 if dt == SPAM_F64 else _lib.load().spam_csr_download_f32
+        check(fn(self._h, _vp(offsets), None, None))
+        return offsets
+
     # -- products -----------------------------------------------------------------------------
     def spmv_dev(self, x_ptr: int, y_ptr: int):
         check(_lib.load().spam_spmv_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))

@@ -4,7 +4,10 @@
 // (lib.rs:47-81).  Nothing here is arithmetic; the kernels only narrow/widen indices (usize <-> u32, the
 // truncation the reference performs per product at mul_hash.rs:92,157 happens ONCE here) and validate.
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "spam_internal.hpp"
@@ -25,6 +28,60 @@ int set_error(int code, const char* fmt, ...) {
 }
 void clear_error() { g_err.clear(); }
 hipStream_t stream() { return g_stream; }
+
+// ---- caching device allocator ---------------------------------------------------------------------
+static std::mutex g_pool_mu;
+static std::multimap<size_t, void*> g_pool_free;        // size -> block
+static std::unordered_map<void*, size_t> g_pool_sizes;  // every live block handed out or cached
+
+int dev_alloc(void** out, size_t bytes) {
+  const size_t n = (bytes + 255) & ~(size_t)255;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_free.lower_bound(n);
+    if (it != g_pool_free.end() && it->first <= n + n / 4 + (1u << 20)) {  // at most 25 % (+1 MiB) slack
+      *out = it->second;
+      g_pool_free.erase(it);
+      return SPAM_OK;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    dev_trim();  // give cached blocks back and retry once
+    e = hipMalloc(&p, n);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *out = nullptr;
+    return set_error(SPAM_E_OOM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+  }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool_sizes[p] = n;
+  *out = p;
+  return SPAM_OK;
+}
+
+void dev_free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_pool_sizes.find(p);
+  if (it == g_pool_sizes.end()) {
+    (void)hipFree(p);
+    return;
+  }
+  g_pool_free.emplace(it->second, p);
+}
+
+void dev_trim() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (auto& kv : g_pool_free) {
+    g_pool_sizes.erase(kv.second);
+    (void)hipFree(kv.second);
+  }
+  g_pool_free.clear();
+}
 
 // ---- index narrowing / widening ------------------------------------------------------------------
 __global__ void narrow_u64_u32_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
@@ -255,6 +312,13 @@ int spam_hip_set_stream(void* hip_stream) {
   return SPAM_OK;
 }
 
+int spam_hip_trim(void) {
+  clear_error();
+  SPAM_HIP_TRY(hipStreamSynchronize(stream()));
+  dev_trim();
+  return SPAM_OK;
+}
+
 int spam_hip_synchronize(void) {
   clear_error();
   SPAM_HIP_TRY(hipStreamSynchronize(stream()));
@@ -431,11 +495,11 @@ int spam_csr_invariants(const spam_csr* m, int* ok) {
 void spam_csr_free(spam_csr* m) {
   if (!m) return;
   if (m->spmv_plan) spmv_plan_free(m->spmv_plan);
-  if (m->owns_row_ptr && m->row_ptr) (void)hipFree(m->row_ptr);
-  if (m->owns_row_ptr32 && m->row_ptr32) (void)hipFree(m->row_ptr32);
+  if (m->owns_row_ptr && m->row_ptr) dev_free(m->row_ptr);
+  if (m->owns_row_ptr32 && m->row_ptr32) dev_free(m->row_ptr32);
   if (m->owns_col_val) {
-    if (m->col_idx) (void)hipFree(m->col_idx);
-    if (m->vals) (void)hipFree(m->vals);
+    if (m->col_idx) dev_free(m->col_idx);
+    if (m->vals) dev_free(m->vals);
   }
   delete m;
 }

@@ -40,6 +40,14 @@ void clear_error();
 
 hipStream_t stream();
 
+// Caching device allocator: freed blocks are kept and handed back to later requests of a similar size, so a
+// product repeated on same-sized operands pays hipMalloc (seconds for a 100 GB C) only once — the same
+// steady state the reference's Vec::with_capacity gets from the process allocator (mul_hash.rs:119).
+// spam_hip_trim() returns everything to the driver.
+int dev_alloc(void** p, size_t bytes);
+void dev_free(void* p);
+void dev_trim();
+
 // RAII device buffer (frees on scope exit unless released)
 struct DevBuf {
   void* p = nullptr;
@@ -52,16 +60,10 @@ struct DevBuf {
     reset();
     bytes = n;
     if (n == 0) n = 16;
-    hipError_t e = hipMalloc(&p, n);
-    if (e != hipSuccess) {
-      p = nullptr;
-      (void)hipGetLastError();
-      return set_error(SPAM_E_OOM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
-    }
-    return SPAM_OK;
+    return dev_alloc(&p, n);
   }
   void reset() {
-    if (p) (void)hipFree(p);
+    if (p) dev_free(p);
     p = nullptr;
     bytes = 0;
   }

@@ -36,6 +36,8 @@ constexpr int SCW_SHIFT = 17;
 constexpr uint32_t SCW = 1u << SCW_SHIFT;       // symbolic chunk: 131072 byte flags (128 KB)
 constexpr int SC_PER = SCW / CW;                // numeric chunks per symbolic chunk (8)
 
+constexpr uint32_t HEAVY_GRID = 8192;           // persistent workgroups of the heavy kernels (1 fits per CU)
+
 constexpr int NSYM = 4;                         // symbolic bins by F
 constexpr uint64_t SYM_MAX[NSYM - 1] = {64, 512, 4096};
 constexpr int NNUM = 5;                         // numeric bins by nnz(C_i)
@@ -214,55 +216,132 @@ __global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ 
   }
 }
 
-// One workgroup per (heavy row, symbolic chunk): set a byte flag per produced column, then count per
-// numeric chunk.  No atomics on the flags: every writer stores the same value.
+// ---- flattened product space for the heavy kernels ---------------------------------------------------
+// A batch of up to SEG entries k of A's row gives SEG segments [lo_s, lo_s + len_s) of B's arrays.  Their
+// lengths are prefix-summed into LDS (seg_start) and the workgroup then walks the concatenated product
+// index space: thread t takes HEAVY_U consecutive products per round (one binary search, then a forward
+// walk over segment boundaries), so lanes stay busy whatever the mix of short and long B rows, and each
+// lane has HEAVY_U independent loads in flight.
+constexpr int HEAVY_U = 8;
+
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wsum /* [17] */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();  // wsum may still be read from the previous call
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t c = wsum[i];
+    if (i < w) off += c;
+    tot += c;
+  }
+  if (threadIdx.x == 0) wsum[16] = tot;
+  return off + inc - v;
+}
+
+// largest s in [0, n) with seg_start[s] <= idx   (seg_start is non-decreasing, seg_start[0] = 0)
+__device__ __forceinline__ uint32_t seg_find(const uint32_t* seg_start, uint32_t n, uint32_t idx) {
+  uint32_t lo = 0, hi = n;  // invariant: seg_start[lo] <= idx, answer in [lo, hi)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (seg_start[mid] <= idx)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// Workgroups loop over (heavy row, symbolic chunk) items: set a byte flag per produced column, then count
+// per numeric chunk.  No atomics on the flags: every writer stores the same value.
 template <bool USE_BPOS>
 __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restrict__ a_rp,
                                                         const uint32_t* __restrict__ a_col,
                                                         const uint64_t* __restrict__ b_rp,
                                                         const uint32_t* __restrict__ b_col,
                                                         const uint32_t* __restrict__ bpos, uint32_t rows_b,
-                                                        const uint32_t* __restrict__ heavy_rows, uint32_t nsc,
-                                                        uint32_t nchunks, uint32_t* __restrict__ hcnt) {
+                                                        const uint32_t* __restrict__ heavy_rows, uint32_t n_items,
+                                                        uint32_t nsc, uint32_t nchunks, uint32_t* __restrict__ hcnt) {
+  constexpr int SEG = 1024;
   __shared__ __attribute__((aligned(16))) uint8_t flags[SCW];
+  __shared__ uint32_t seg_start[SEG + 1];
+  __shared__ uint32_t seg_lo[SEG];
+  __shared__ uint32_t wsum[17];
   __shared__ uint32_t ccnt[SC_PER];
-  const uint32_t hrow = blockIdx.x / nsc, sc = blockIdx.x % nsc;
-  const uint32_t row = heavy_rows[hrow];
-  const uint32_t c0 = sc << SCW_SHIFT;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4* f4 = (u32x4*)flags;
   for (int i = threadIdx.x; i < (int)(SCW / 16); i += 1024) f4[i] = (u32x4)(0u);
   if (threadIdx.x < SC_PER) ccnt[threadIdx.x] = 0;
   __syncthreads();
-  const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
-  // lanes per B row: wide when the A row is short (its B rows are then the long ones)
-  uint32_t S = 1024u / next_pow2_u32((uint32_t)std::min<uint64_t>(pe - ps, 1024));
-  S = S < 16 ? 16 : S;
-  const uint32_t sub = threadIdx.x / S, sl = threadIdx.x % S, nsub = 1024 / S;
-  const uint32_t j0 = sc * SC_PER, j1 = (j0 + SC_PER < nchunks) ? j0 + SC_PER : nchunks;
-  for (uint64_t p = ps + sub; p < pe; p += nsub) {
-    const uint32_t k = a_col[p];
-    if (USE_BPOS) {
-      const uint32_t lo = bpos[(uint64_t)j0 * rows_b + k], hi = bpos[(uint64_t)j1 * rows_b + k];
-      for (uint32_t q = lo + sl; q < hi; q += S) flags[b_col[q] - c0] = 1;
-    } else {
-      for (uint64_t q = b_rp[k] + sl, qe = b_rp[k + 1]; q < qe; q += S) {
-        const uint32_t c = b_col[q] - c0;
-        if (c < SCW) flags[c] = 1;
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t hrow = item / nsc, sc = item % nsc;
+    const uint32_t row = heavy_rows[hrow];
+    const uint32_t c0 = sc << SCW_SHIFT;
+    const uint32_t j0 = sc * SC_PER, j1 = (j0 + SC_PER < nchunks) ? j0 + SC_PER : nchunks;
+    const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
+    for (uint64_t pb = ps; pb < pe; pb += SEG) {
+      const uint64_t p = pb + threadIdx.x;
+      uint32_t lo = 0, len = 0;
+      if (p < pe) {
+        const uint32_t k = a_col[p];
+        if (USE_BPOS) {
+          lo = bpos[(uint64_t)j0 * rows_b + k];
+          len = bpos[(uint64_t)j1 * rows_b + k] - lo;
+        } else {
+          lo = (uint32_t)b_rp[k];
+          len = (uint32_t)b_rp[k + 1] - lo;
+        }
       }
-    }
-  }
-  __syncthreads();
-  // iteration i covers exactly numeric chunk j0 + i: 1024 threads x 16 flags = CW
+      const uint32_t st = block_excl_scan_1024(len, wsum);
+      seg_start[threadIdx.x] = st;
+      seg_lo[threadIdx.x] = lo;
+      __syncthreads();
+      const uint32_t total = wsum[16];
+      if (threadIdx.x == 0) seg_start[SEG] = total;
+      __syncthreads();
+      for (uint32_t base = threadIdx.x * HEAVY_U; base < total; base += 1024 * HEAVY_U) {
+        uint32_t sg = seg_find(seg_start, SEG, base);
+        uint32_t cols[HEAVY_U];
 #pragma unroll
-  for (int i = 0; i < SC_PER; ++i) {
-    const u32x4 w = f4[i * 1024 + threadIdx.x];
-    uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
-    n = wave_sum_u32(n);
-    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&ccnt[i], n);
+        for (int j = 0; j < HEAVY_U; ++j) {
+          const uint32_t idx = base + j;
+          cols[j] = 0xFFFFFFFFu;
+          if (idx < total) {
+            while (idx >= seg_start[sg + 1]) ++sg;
+            cols[j] = b_col[seg_lo[sg] + (idx - seg_start[sg])];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < HEAVY_U; ++j) {
+          const uint32_t c = cols[j] - c0;
+          if (cols[j] != 0xFFFFFFFFu && c < SCW) flags[c] = 1;
+        }
+      }
+      __syncthreads();
+    }
+    // iteration i covers exactly numeric chunk j0 + i: 1024 threads x 16 flags = CW; flags are reset here
+#pragma unroll
+    for (int i = 0; i < SC_PER; ++i) {
+      const u32x4 w = f4[i * 1024 + threadIdx.x];
+      uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+      if (n) f4[i * 1024 + threadIdx.x] = (u32x4)(0u);
+      n = wave_sum_u32(n);
+      if ((threadIdx.x & 63) == 0 && n) atomicAdd(&ccnt[i], n);
+    }
+    __syncthreads();
+    if (threadIdx.x < SC_PER) {
+      if (j0 + threadIdx.x < nchunks) hcnt[(uint64_t)hrow * nchunks + j0 + threadIdx.x] = ccnt[threadIdx.x];
+      ccnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (threadIdx.x < SC_PER && j0 + threadIdx.x < nchunks) hcnt[(uint64_t)hrow * nchunks + j0 + threadIdx.x] = ccnt[threadIdx.x];
 }
 
 // per heavy row: hoff = exclusive prefix of hcnt over chunks, row_nnz = total.  One wavefront per row.
@@ -389,79 +468,103 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void num_hash_kernel(
   }
 }
 
-// One workgroup per non-empty (heavy row, numeric chunk): dense accumulator over CW columns in LDS.
+// Workgroups loop over the non-empty (heavy row, numeric chunk) items: dense accumulator over CW columns in
+// LDS (LDS float atomics), byte flags for the pattern, compaction in column order (so heavy rows are sorted).
 template <class T, bool USE_BPOS>
 __global__ __launch_bounds__(1024) void num_heavy_kernel(
     const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
     const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col, const T* __restrict__ b_val,
     const uint32_t* __restrict__ bpos, uint32_t rows_b, const uint32_t* __restrict__ heavy_rows,
-    const uint64_t* __restrict__ items, uint32_t nchunks, const uint32_t* __restrict__ hoff,
+    const uint64_t* __restrict__ items, uint32_t n_items, uint32_t nchunks, const uint32_t* __restrict__ hoff,
     const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ c_col, T* __restrict__ c_val) {
+  constexpr int SEG = 512;
   __shared__ __attribute__((aligned(16))) T acc[CW];
   __shared__ __attribute__((aligned(16))) uint8_t flags[CW];
-  __shared__ uint32_t wcnt[16];
-  const uint64_t it = items[blockIdx.x];
-  const uint32_t hrow = (uint32_t)(it >> 32), chunk = (uint32_t)it;
-  const uint32_t row = heavy_rows[hrow];
-  const uint32_t c0 = chunk << CW_SHIFT;
+  __shared__ uint32_t seg_start[SEG + 1];
+  __shared__ uint32_t seg_lo[SEG];
+  __shared__ T seg_av[SEG];
+  __shared__ uint32_t wsum[17];
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4* f4 = (u32x4*)flags;
   f4[threadIdx.x] = (u32x4)(0u);  // 1024 x 16 = CW flags
   for (int i = threadIdx.x; i < (int)CW; i += 1024) acc[i] = T(0);
   __syncthreads();
-  const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
-  uint32_t S = 1024u / next_pow2_u32((uint32_t)std::min<uint64_t>(pe - ps, 1024));
-  S = S < 16 ? 16 : S;
-  const uint32_t sub = threadIdx.x / S, sl = threadIdx.x % S, nsub = 1024 / S;
-  for (uint64_t p = ps + sub; p < pe; p += nsub) {
-    const uint32_t k = a_col[p];
-    const T av = a_val[p];
-    if (USE_BPOS) {
-      const uint32_t lo = bpos[(uint64_t)chunk * rows_b + k], hi = bpos[(uint64_t)(chunk + 1) * rows_b + k];
-      for (uint32_t q = lo + sl; q < hi; q += S) {
-        const uint32_t c = b_col[q] - c0;
-        atomicAdd(&acc[c], av * b_val[q]);
-        flags[c] = 1;
+  for (uint32_t ii = blockIdx.x; ii < n_items; ii += gridDim.x) {
+    const uint64_t it = items[ii];
+    const uint32_t hrow = (uint32_t)(it >> 32), chunk = (uint32_t)it;
+    const uint32_t row = heavy_rows[hrow];
+    const uint32_t c0 = chunk << CW_SHIFT;
+    const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
+    for (uint64_t pb = ps; pb < pe; pb += SEG) {
+      const uint64_t p = pb + threadIdx.x;
+      uint32_t lo = 0, len = 0;
+      if (threadIdx.x < SEG && p < pe) {
+        const uint32_t k = a_col[p];
+        seg_av[threadIdx.x] = a_val[p];
+        if (USE_BPOS) {
+          lo = bpos[(uint64_t)chunk * rows_b + k];
+          len = bpos[(uint64_t)(chunk + 1) * rows_b + k] - lo;
+        } else {
+          lo = (uint32_t)b_rp[k];
+          len = (uint32_t)b_rp[k + 1] - lo;
+        }
       }
-    } else {
-      for (uint64_t q = b_rp[k] + sl, qe = b_rp[k + 1]; q < qe; q += S) {
-        const uint32_t c = b_col[q] - c0;
-        if (c < CW) {
-          atomicAdd(&acc[c], av * b_val[q]);
-          flags[c] = 1;
+      const uint32_t st = block_excl_scan_1024(len, wsum);
+      if (threadIdx.x < SEG) {
+        seg_start[threadIdx.x] = st;
+        seg_lo[threadIdx.x] = lo;
+      }
+      __syncthreads();
+      const uint32_t total = wsum[16];
+      if (threadIdx.x == 0) seg_start[SEG] = total;
+      __syncthreads();
+      for (uint32_t base = threadIdx.x * HEAVY_U; base < total; base += 1024 * HEAVY_U) {
+        uint32_t sg = seg_find(seg_start, SEG, base);
+        uint32_t cols[HEAVY_U];
+        T prods[HEAVY_U];
+#pragma unroll
+        for (int j = 0; j < HEAVY_U; ++j) {
+          const uint32_t idx = base + j;
+          cols[j] = 0xFFFFFFFFu;
+          prods[j] = T(0);
+          if (idx < total) {
+            while (idx >= seg_start[sg + 1]) ++sg;
+            const uint32_t q = seg_lo[sg] + (idx - seg_start[sg]);
+            cols[j] = b_col[q];
+            prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < HEAVY_U; ++j) {
+          const uint32_t c = cols[j] - c0;
+          if (cols[j] != 0xFFFFFFFFu && c < CW) {
+            atomicAdd(&acc[c], prods[j]);
+            flags[c] = 1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // compaction in column order: thread t owns columns [16 t, 16 t + 16); touched slots are reset here
+    const u32x4 w = f4[threadIdx.x];
+    const uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+    const uint32_t ex = block_excl_scan_1024(n, wsum);
+    if (n) {
+      uint64_t out = c_rp[row] + hoff[(uint64_t)hrow * nchunks + chunk] + ex;
+      f4[threadIdx.x] = (u32x4)(0u);
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if ((ww[j >> 2] >> ((j & 3) * 8)) & 1u) {
+          const uint32_t c = threadIdx.x * 16 + j;
+          c_col[out] = c0 + c;
+          c_val[out] = acc[c];
+          acc[c] = T(0);
+          ++out;
         }
       }
     }
-  }
-  __syncthreads();
-  // compaction in column order: thread t owns columns [16 t, 16 t + 16)
-  const u32x4 w = f4[threadIdx.x];
-  const uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint32_t inc = n;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  if (lane == 63) wcnt[wv] = inc;
-  __syncthreads();
-  uint32_t off = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-    if (i < wv) off += wcnt[i];
-  uint64_t out = c_rp[row] + hoff[(uint64_t)hrow * nchunks + chunk] + off + inc - n;
-  if (n) {
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if ((ww[j >> 2] >> ((j & 3) * 8)) & 1u) {
-        const uint32_t c = threadIdx.x * 16 + j;
-        c_col[out] = c0 + c;
-        c_val[out] = acc[c];
-        ++out;
-      }
-    }
+    __syncthreads();
   }
 }
 
@@ -659,7 +762,9 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     SPAM_TRY(p->heavy_rows.alloc((uint64_t)p->n_heavy * 4));
     SPAM_HIP_TRY(hipMemcpyAsync(p->heavy_rows.p, L + (uint64_t)(NSYM - 1) * rows, (uint64_t)p->n_heavy * 4,
                                 hipMemcpyDeviceToDevice, s));
-    p->use_bpos = b->is_sorted && p->nchunks > 1 && b->nnz < (1ull << 32);
+    if (b->nnz >= (1ull << 32))
+      return set_error(SPAM_E_UNSUPPORTED, "rows with more than 4096 intermediate products need nnz(B) < 2^32");
+    p->use_bpos = b->is_sorted && p->nchunks > 1;
     if (p->use_bpos) {
       SPAM_TRY(p->bpos.alloc((uint64_t)(p->nchunks + 1) * b->rows * 4));
       unsigned grid = (unsigned)std::min<uint64_t>((b->rows + 3) / 4, 16384);
@@ -668,15 +773,16 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     }
     SPAM_TRY(p->hcnt.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
     SPAM_TRY(p->hoff.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
-    const unsigned grid = p->n_heavy * p->nsc;
+    const uint32_t n_sym_items = p->n_heavy * p->nsc;
+    const unsigned grid = std::min<uint32_t>(n_sym_items, HEAVY_GRID);  // gridDim.x * 1024 must stay below 2^32
     if (p->use_bpos)
       sym_heavy_kernel<true><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, p->bpos.as<uint32_t>(),
-                                                   (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->nsc, p->nchunks,
-                                                   p->hcnt.as<uint32_t>());
+                                                   (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), n_sym_items, p->nsc,
+                                                   p->nchunks, p->hcnt.as<uint32_t>());
     else
       sym_heavy_kernel<false><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, nullptr,
-                                                    (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->nsc, p->nchunks,
-                                                    p->hcnt.as<uint32_t>());
+                                                    (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), n_sym_items, p->nsc,
+                                                    p->nchunks, p->hcnt.as<uint32_t>());
     SPAM_CHECK_LAUNCH();
     heavy_finalize_kernel<<<(p->n_heavy + 3) / 4, 256, 0, s>>>(p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
                                                               p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn);
@@ -755,16 +861,17 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     st.heavy_items = n_items;
     if (n_items >= (1ull << 31)) return set_error(SPAM_E_UNSUPPORTED, "too many heavy (row, chunk) items for one launch");
     if (n_items) {
+      const unsigned hgrid = (unsigned)std::min<unsigned long long>(n_items, HEAVY_GRID);
       if (p->use_bpos)
-        num_heavy_kernel<T, true><<<(unsigned)n_items, 1024, 0, s>>>(
+        num_heavy_kernel<T, true><<<hgrid, 1024, 0, s>>>(
             a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals, p->bpos.as<uint32_t>(),
-            (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), items.as<uint64_t>(), p->nchunks, p->hoff.as<uint32_t>(),
-            crp, cc, cv);
+            (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), items.as<uint64_t>(), (uint32_t)n_items, p->nchunks,
+            p->hoff.as<uint32_t>(), crp, cc, cv);
       else
-        num_heavy_kernel<T, false><<<(unsigned)n_items, 1024, 0, s>>>(
+        num_heavy_kernel<T, false><<<hgrid, 1024, 0, s>>>(
             a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals, nullptr,
-            (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), items.as<uint64_t>(), p->nchunks, p->hoff.as<uint32_t>(),
-            crp, cc, cv);
+            (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), items.as<uint64_t>(), (uint32_t)n_items, p->nchunks,
+            p->hoff.as<uint32_t>(), crp, cc, cv);
       SPAM_CHECK_LAUNCH();
     }
     SPAM_HIP_TRY(hipStreamSynchronize(s));  // items is freed at scope exit

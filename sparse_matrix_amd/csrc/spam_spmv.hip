@@ -33,8 +33,8 @@ struct SpmvPlan {
 
 void spmv_plan_free(SpmvPlan* p) {
   if (!p) return;
-  if (p->first_owned) (void)hipFree(p->first_owned);
-  if (p->carry) (void)hipFree(p->carry);
+  if (p->first_owned) dev_free(p->first_owned);
+  if (p->carry) dev_free(p->carry);
   delete p;
 }
 
@@ -221,8 +221,8 @@ static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, 
     SPAM_CHECK_LAUNCH();
     return SPAM_OK;
   }
-  static const int npt_cfg = env_int("SPAM_SPMV_NPT", 16);
-  static const int nt_cfg = env_int("SPAM_SPMV_NT", 0);
+  const int npt_cfg = env_int("SPAM_SPMV_NPT", 16);  // read per call so one process can A/B variants
+  const int nt_cfg = env_int("SPAM_SPMV_NT", 0);
   const int npt = (npt_cfg == 8) ? 8 : 16;
   const uint32_t tile = SPMV_TPB * npt;
   spam_csr* am = const_cast<spam_csr*>(a);
