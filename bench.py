@@ -31,6 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from sparse_matrix_amd import DeviceCsr, _lib, synth  # noqa: E402
+from sparse_matrix_amd import dist as spdist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling there: 6290 GB/s
 
@@ -57,7 +58,8 @@ def main():
     ap.add_argument("--spmv-rows", type=int, default=10_000_000)
     ap.add_argument("--spmv-nnz", type=int, default=160_000_000)
     ap.add_argument("--spmv-oversample", type=float, default=1.30)
-    ap.add_argument("--spgemm-scale", type=int, default=-1, help="-1: 18 (1 GPU default run); 0 disables")
+    ap.add_argument("--spgemm-scale", type=int, default=20, help="R-MAT scale of C = A*A (configs[2]); 0 disables; "
+                    "22 (configs[3]) needs >= 8 GPUs: nnz(C) ~ 8e10 does not fit one")
     ap.add_argument("--spgemm-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv", action="store_true")
@@ -68,15 +70,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SPAM_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box); the real run is nccl = RCCL
+    backend = os.environ.get("SPAM_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_
 
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
-    _lib.ensure_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    _lib.ensure_device(dev_index)
     L = _lib.load()
     _lib.check(L.spam_hip_set_stream(torch.cuda.current_stream().cuda_stream))
 
@@ -165,49 +173,30 @@ def main():
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ SpGEMM (secondary) ---------
-    scale = args.spgemm_scale if args.spgemm_scale >= 0 else 18
+    scale = args.spgemm_scale
     if scale > 0:
         n = 1 << scale
         # every rank starts with an equal row block of A (= its block of B); values depend on global coordinates
-        lo, hi = rank * n // world, (rank + 1) * n // world
+        lo, hi = spdist.equal_row_block(n, rank, world)
         t0 = time.time()
         blk = synth.rmat(scale, dtype=torch.float64, device=dev, row_range=(lo, hi) if world > 1 else None)
         torch.cuda.synchronize()
         log(f"[spgemm] rank block rows [{lo},{hi}) nnz {blk.nnz} generated in {time.time() - t0:.1f}s")
 
         def one_step():
-            """all-gather B, flop-balanced row block of A, local two-phase SpGEMM.  Returns (C, stats, ms)."""
+            """all-gather B, flop-balanced row block of A, local two-phase SpGEMM.  Returns (C, stats)."""
+            rp, col, val = spdist.allgather_csr(blk.row_ptr, blk.col_idx, blk.vals, n, rank, world, dist)
+            B = DeviceCsr.from_torch(n, n, rp, col, val, True)
             if world > 1:
-                sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-                sizes[rank] = blk.nnz
-                dist.all_reduce(sizes)
-                nnz_tot = int(sizes.sum().item())
-                starts = torch.cumsum(sizes, 0) - sizes
-                col = torch.empty(nnz_tot, dtype=torch.int32, device=dev)
-                val = torch.empty(nnz_tot, dtype=torch.float64, device=dev)
-                rp = torch.empty(n + 1, dtype=torch.int64, device=dev)
-                s0 = int(starts[rank].item())
-                col[s0:s0 + blk.nnz] = blk.col_idx
-                val[s0:s0 + blk.nnz] = blk.vals
-                rp[lo:hi] = blk.row_ptr[:-1] + s0  # row_ptr fix-up by the rank's global offset
-                rp[n] = nnz_tot
-                # all-gather-v as grouped broadcasts (unequal shards)
-                for r in range(world):
-                    a0, a1 = int(starts[r].item()), int(starts[r].item() + sizes[r].item())
-                    r0, r1 = r * n // world, (r + 1) * n // world
-                    dist.broadcast(col[a0:a1], src=r)
-                    dist.broadcast(val[a0:a1], src=r)
-                    dist.broadcast(rp[r0:r1], src=r)
-                B = DeviceCsr.from_torch(n, n, rp, col, val, True)
-                _, offs = B.rows_to_parts(B, world)
+                _, offs = B.rows_to_parts(B, world)  # rows_to_threads with tnum = world (mul_hash.rs:38-64)
                 mylo, myhi = int(offs[rank]), int(offs[rank + 1])
-                Ablk = B.row_block(mylo, myhi) if myhi > mylo else None
+                if myhi <= mylo:
+                    return None, None
+                Ablk = B.row_block(mylo, myhi)
             else:
-                B = DeviceCsr.from_torch(n, n, blk.row_ptr, blk.col_idx, blk.vals, True)
                 Ablk = B
-            if Ablk is None:
-                return None, None
             C, st = Ablk.spgemm(B, sort_rows=False)
+            C._keep = (C._keep, B, Ablk)
             return C, st
 
         C, st = one_step()  # warm-up (also sizes the problem)

@@ -1,0 +1,75 @@
+"""Row-sharded multi-GPU SpGEMM plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI; "gloo" for CPU tests and single-GPU rehearsals).
+
+The reference is single-process; its only partition is rows_to_threads (spam_csr/src/mul_hash.rs:38-64),
+contiguous row ranges balanced by intermediate products.  The same rule cuts A across GPUs (tnum = world
+size).  C's rows depend on the matching rows of A and ALL of B, so the one exchange step is an all-gather
+of B's CSR arrays (row blocks are unequal, so it is an all-gather-v built from per-source broadcasts);
+nothing is reduced and C stays row-sharded.  Everything here works on torch tensors of any device, so the
+logic is exercised on CPU with gloo (tests/test_dist_cpu.py).
+"""
+from __future__ import annotations
+
+import torch
+
+
+def equal_row_block(n_rows: int, rank: int, world: int) -> tuple[int, int]:
+    """Initial distribution: rank r generates / holds rows [r*n/world, (r+1)*n/world)."""
+    return rank * n_rows // world, (rank + 1) * n_rows // world
+
+
+def allgather_csr(row_ptr: torch.Tensor, col_idx: torch.Tensor, vals: torch.Tensor, n_rows: int, rank: int,
+                  world: int, dist=None):
+    """All-gather-v of equal_row_block-distributed CSR blocks into the full matrix on every rank.
+
+    row_ptr int64[rows_local+1] (block-local offsets starting at 0), col_idx int32[nnz_local], vals[nnz_local].
+    Returns (row_ptr int64[n_rows+1], col_idx, vals) with row_ptr globalised by each source's offset.
+    Traffic per rank: receives nnz_total*(4+sizeof T) + n_rows*8 bytes, sends its own block once per peer.
+    """
+    dev = col_idx.device
+    if world == 1 or dist is None:
+        return row_ptr, col_idx, vals
+    nnz_local = int(col_idx.numel())
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    sizes[rank] = nnz_local
+    dist.all_reduce(sizes)
+    sizes_h = sizes.cpu().tolist()
+    starts_h = [0] * world
+    for r in range(1, world):
+        starts_h[r] = starts_h[r - 1] + sizes_h[r - 1]
+    nnz_tot = starts_h[-1] + sizes_h[-1]
+    col = torch.empty(nnz_tot, dtype=col_idx.dtype, device=dev)
+    val = torch.empty(nnz_tot, dtype=vals.dtype, device=dev)
+    rp = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+    lo, hi = equal_row_block(n_rows, rank, world)
+    s0 = starts_h[rank]
+    col[s0:s0 + nnz_local] = col_idx
+    val[s0:s0 + nnz_local] = vals
+    rp[lo:hi] = row_ptr[:-1] + s0  # row_ptr fix-up by the source rank's global nnz offset
+    rp[n_rows] = nnz_tot
+    for r in range(world):  # unequal shards: one broadcast per source and array
+        r0, r1 = equal_row_block(n_rows, r, world)
+        a0, a1 = starts_h[r], starts_h[r] + sizes_h[r]
+        if a1 > a0:
+            dist.broadcast(col[a0:a1], src=r)
+            dist.broadcast(val[a0:a1], src=r)
+        if r1 > r0:
+            dist.broadcast(rp[r0:r1], src=r)
+    return rp, col, val
+
+
+def rows_to_parts_host(row_flops: torch.Tensor, nparts: int) -> list[int]:
+    """rows_to_threads' partition rule on a vector of per-row intermediate-product counts
+    (mul_hash.rs:51-62): ps = [0, cumsum], average = ceil(total / nparts),
+    offsets[t] = partition_point(ps, x <= average * t) - 1."""
+    f = row_flops.to(torch.int64).cpu()
+    ps = torch.zeros(f.numel() + 1, dtype=torch.int64)
+    torch.cumsum(f, 0, out=ps[1:])
+    total = int(ps[-1].item())
+    avg = -(-total // nparts)
+    offs = [0]
+    for t in range(1, nparts):
+        pp = int(torch.searchsorted(ps, torch.tensor([avg * t], dtype=torch.int64), right=True).item())
+        offs.append(pp - 1)
+    offs.append(f.numel())
+    return offs

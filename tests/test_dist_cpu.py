@@ -1,0 +1,73 @@
+"""The multi-GPU path's host logic on CPU: 2 ranks over gloo (no GPU, no RCCL).
+
+What runs across ranks in bench.py is (1) the all-gather-v of B's CSR row blocks with row_ptr fix-up and
+(2) the flop-balanced row split (rows_to_threads with tnum = world, mul_hash.rs:38-64).  Here the local
+product is the CPU oracle (allowed in tests); on the GPU box it is libspam_hip.so.
+"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sparse_matrix_amd import dist as spdist, synth
+
+SCALE = 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    import oracle
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1 << SCALE
+        lo, hi = spdist.equal_row_block(n, rank, world)
+        blk = synth.rmat(SCALE, row_range=(lo, hi) if world > 1 else None)
+        rp, col, val = spdist.allgather_csr(blk.row_ptr, blk.col_idx, blk.vals, n, rank, world, dist)
+        full = synth.rmat(SCALE)
+        assert torch.equal(rp, full.row_ptr) and torch.equal(col, full.col_idx) and torch.equal(val, full.vals)
+        a = (rp.numpy().astype(np.uint64), col.numpy().astype(np.uint64), val.numpy())
+        flops, offs_ref = oracle.rows_to_threads(a[0], a[1], a[0], world)
+        offs = spdist.rows_to_parts_host(torch.from_numpy(flops.astype(np.int64)), world)
+        assert offs == offs_ref.tolist()
+        mylo, myhi = offs[rank], offs[rank + 1]
+        sub = (a[0][mylo:myhi + 1] - a[0][mylo], a[1][int(a[0][mylo]):int(a[0][myhi])], a[2][int(a[0][mylo]):int(a[0][myhi])])
+        o, i, v = oracle.mul_hash(sub, a, sort_rows=True, tnum=1)
+        # every rank checks its block against the single-process product
+        wo, wi, wv = oracle.mul_hash(a, a, sort_rows=True, tnum=1)
+        s, e = int(wo[mylo]), int(wo[myhi])
+        assert np.array_equal(o, wo[mylo:myhi + 1] - wo[mylo]) and np.array_equal(i, wi[s:e]) and np.array_equal(v, wv[s:e])
+        # C's global row_ptr from one all-gather of per-rank nnz counts
+        cnt = torch.zeros(world, dtype=torch.int64)
+        cnt[rank] = len(i)
+        dist.all_reduce(cnt)
+        assert int(cnt.sum()) == len(wi)
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_allgather_and_partition():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_partition_rule_edge_cases():
+    """total = 0 and single-row cases of the partition_point rule (mul_hash.rs:55-62)."""
+    assert spdist.rows_to_parts_host(torch.tensor([0, 0, 0]), 2) == [0, 3, 3]
+    assert spdist.rows_to_parts_host(torch.tensor([5]), 3) == [0, 0, 0, 1]
+    assert spdist.rows_to_parts_host(torch.tensor([1, 1, 1, 1]), 2) == [0, 2, 4]

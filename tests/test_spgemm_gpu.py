@@ -170,3 +170,31 @@ def test_row_block_product_equals_slice(spam, oracle):
         wo = want[0][lo:hi + 1] - want[0][lo]
         s, e = int(want[0][lo]), int(want[0][hi])
         assert_csr_parity((o, i, v), (wo, want[1][s:e], want[2][s:e]), True, F64_RTOL)
+
+
+def test_full_size_row_sum_property(spam):
+    """BASELINE-size check that needs no CPU product: (A*A)*1 == A*(A*1) row by row at R-MAT scale 19
+    (F = 7.9e9 products, nnz(C) = 3.5e9, beyond 2^31 work items on the heavy path), sorted and unsorted
+    output, plus invariants 1-7 of the sorted result on the device."""
+    import torch
+    from sparse_matrix_amd import DeviceCsr
+
+    dev = torch.device("cuda", 0)
+    A = synth.rmat(19, dtype=torch.float64, device=dev)
+    dA = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, A.vals, True)
+    ones = torch.ones(A.cols, dtype=torch.float64, device=dev)
+    t1, t2, t3 = (torch.empty(A.rows, dtype=torch.float64, device=dev) for _ in range(3))
+    dA.spmv_dev(ones.data_ptr(), t1.data_ptr())
+    dA.spmv_dev(t1.data_ptr(), t2.data_ptr())
+    for sort_rows in (False, True):
+        C, st = dA.spgemm(dA, sort_rows=sort_rows)
+        assert st["nnz_c"] > 3_000_000_000 and st["flops_f"] > 7_000_000_000
+        C.spmv_dev(ones.data_ptr(), t3.data_ptr())
+        torch.cuda.synchronize()
+        rel = ((t3 - t2).abs() / t2.abs().clamp_min(1e-300)).max().item()
+        assert rel <= F64_RTOL, rel
+        if sort_rows:
+            assert C.invariants()
+        rp = C.download_row_ptr().astype(np.int64)
+        assert rp[0] == 0 and rp[-1] == st["nnz_c"] and np.all(np.diff(rp) >= 0)
+        C.free()

@@ -122,3 +122,35 @@ def test_wrong_x_length_is_an_error(spam):
     A = spam.CsrMatrix.identity(4)
     with pytest.raises(spam.SpamError):
         A.spmv(np.ones(5))
+
+
+def test_cfg2_full_size_linearity_and_third_party(spam, oracle):
+    """BASELINE configs[1] at full size (10 M rows, ~160 M nnz, f64), device-resident:
+    linearity A(x + 2z) == Ax + 2Az, agreement with torch.sparse (hipSPARSE, an independent third party),
+    and the oracle on the whole matrix (0.1 s on the box's cores)."""
+    from sparse_matrix_amd import DeviceCsr
+
+    dev = torch.device("cuda", 0)
+    A = synth.rmat_rect(10_000_000, 160_000_000, dtype=torch.float64, device=dev, oversample=1.30)
+    assert 150_000_000 < A.nnz < 175_000_000
+    dA = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, A.vals, True)
+    x = synth.dense_vector(A.cols, seed=7, device=dev)
+    z = synth.dense_vector(A.cols, seed=8, device=dev)
+    yx, yz, yc = (torch.empty(A.rows, dtype=torch.float64, device=dev) for _ in range(3))
+    dA.spmv_dev(x.data_ptr(), yx.data_ptr())
+    dA.spmv_dev(z.data_ptr(), yz.data_ptr())
+    comb = x + 2 * z
+    dA.spmv_dev(comb.data_ptr(), yc.data_ptr())
+    torch.cuda.synchronize()
+    ref = yx + 2 * yz
+    nz = ref != 0
+    assert ((yc - ref).abs()[nz] / ref.abs()[nz]).max().item() <= F64_RTOL
+    assert torch.all(yc[~nz] == 0)
+    S = torch.sparse_csr_tensor(A.row_ptr, A.col_idx.to(torch.int64), A.vals, size=(A.rows, A.cols))
+    yt = torch.mv(S, x) if hasattr(torch, "mv") else S @ x
+    assert ((yt - yx).abs()[nz] / yx.abs()[nz]).max().item() <= F64_RTOL
+    del S, yt
+    yo = oracle.spmv(A.cpu_numpy(), x.cpu().numpy(), nthreads=oracle.hardware_threads())
+    yh = yx.cpu().numpy()
+    m = yo != 0
+    assert (np.abs(yh[m] - yo[m]) / np.abs(yo[m])).max() <= F64_RTOL and np.all(yh[~m] == 0)
