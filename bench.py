@@ -142,6 +142,14 @@ def main():
                          "kernel": "spmv_tile_kernel(+fixup)", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes": nbytes},
         })
+        # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc run (tools/prof_bench.sh), never from this process
+        pmc = os.path.join(ROOT, "profiles", "spmv_pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                out["roofline"]["traffic"] = round(json.load(open(pmc))["traffic_bytes_per_launch"])
+                out["roofline"]["traffic_source"] = "profiles/spmv_pmc_latest.json (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
+            except Exception:
+                pass
         log(f"[spmv] {ms_per_step:.4f} ms/step wall, {kern_ms:.4f} ms device, {achieved:.0f} GB/s "
             f"({100 * achieved / HBM_PEAK_GBPS:.1f}% of 8 TB/s)")
         # parity spot check + CPU baseline: rank 0 at N = 1 only
