@@ -52,7 +52,7 @@ typedef struct spam_spgemm_stats {
   uint64_t flops_f;                /* F = sum of intermediate products (row_nz before symbolic, mul_hash.rs:39-50) */
   uint64_t rows_sym_bin[8];        /* rows per symbolic bin (by F)   */
   uint64_t rows_num_bin[8];        /* rows per numeric bin (by nnz)  */
-  uint64_t heavy_items;            /* (row, column-chunk) work items on the dense-chunk path */
+  uint64_t heavy_items;            /* rows on the heavy (chunked LDS accumulator) numeric path */
   float ms_flops, ms_symbolic, ms_alloc, ms_numeric, ms_total; /* device time, HIP events on the library stream */
 } spam_spgemm_stats;
 

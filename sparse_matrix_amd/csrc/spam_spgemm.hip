@@ -4,11 +4,12 @@
 // accumulator (linprobe/src/{lib,set,map}.rs):
 //   rows_to_threads  :38-64   -> spgemm_flops_kernel (+ host partition in spam_rows_to_parts)
 //   mul_hash_symbolic:66-103  -> sym_hash_kernel<G,S,TABLE> (LDS linprobe set, atomicCAS claim) and
-//                                sym_heavy_kernel (dense byte flags over 131072-column chunks in LDS)
+//                                sym_heavy_kernel (2^20-column bitmap windows in LDS, LDS atomic OR)
 //   checked_inclusive_scan (lib.rs:267-274) -> scan_u32_to_u64
 //   mul_hash_numeric :106-201 -> num_hash_kernel<T,G,S,TABLE> (LDS linprobe map: u32 keys + T values,
-//                                atomicCAS claim + LDS atomic add) and num_heavy_kernel (dense T
-//                                accumulator + byte flags over 16384-column chunks in LDS)
+//                                atomicCAS claim + LDS atomic add) and num_heavy_kernel (per row: dense T
+//                                accumulator over a 16384-column chunk, or one linprobe table shared by a
+//                                run of sparser chunks, both in LDS)
 //   B2 (sort rows)   :164-175 -> sort_rows_kernel (bitonic in LDS); heavy rows come out sorted anyway
 //
 // Where the CPU code gives each thread a contiguous flop-balanced row range (mul_hash.rs:52-62), the GPU
@@ -32,9 +33,6 @@ namespace spam {
 // ---- geometry -------------------------------------------------------------------------------------
 constexpr int CW_SHIFT = 14;
 constexpr uint32_t CW = 1u << CW_SHIFT;         // numeric chunk: 16384 columns (128 KB of f64 + 16 KB flags)
-constexpr int SCW_SHIFT = 17;
-constexpr uint32_t SCW = 1u << SCW_SHIFT;       // symbolic chunk: 131072 byte flags (128 KB)
-constexpr int SC_PER = SCW / CW;                // numeric chunks per symbolic chunk (8)
 
 constexpr uint32_t HEAVY_GRID = 8192;           // persistent workgroups of the heavy kernels (1 fits per CU)
 
@@ -259,88 +257,115 @@ __device__ __forceinline__ uint32_t seg_find(const uint32_t* seg_start, uint32_t
   return lo;
 }
 
-// Workgroups loop over (heavy row, symbolic chunk) items: set a byte flag per produced column, then count
-// per numeric chunk.  No atomics on the flags: every writer stores the same value.
+// forward variant: the answer is >= sg; walk a few segments, then bisect the rest
+__device__ __forceinline__ uint32_t seg_advance(const uint32_t* seg_start, uint32_t n, uint32_t sg, uint32_t idx) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (idx < seg_start[sg + 1]) return sg;
+    ++sg;
+  }
+  uint32_t lo = sg, hi = n;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (seg_start[mid] <= idx)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// Symbolic pass for heavy rows: one workgroup per row, a 2^20-column bitmap window in LDS (LDS atomic OR),
+// then a popcount per numeric chunk.  The row's k list stays in LDS across windows when it fits.
+constexpr int BM_WORDS = 32768;                  // 128 KB bitmap = 2^20 columns = 64 numeric chunks per window
+constexpr int BM_CHUNKS = (BM_WORDS * 32) / CW;  // 64
+constexpr int BM_SHIFT = 20;
+
 template <bool USE_BPOS>
 __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restrict__ a_rp,
                                                         const uint32_t* __restrict__ a_col,
                                                         const uint64_t* __restrict__ b_rp,
                                                         const uint32_t* __restrict__ b_col,
                                                         const uint32_t* __restrict__ bpos, uint32_t rows_b,
-                                                        const uint32_t* __restrict__ heavy_rows, uint32_t n_items,
-                                                        uint32_t nsc, uint32_t nchunks, uint32_t* __restrict__ hcnt) {
+                                                        const uint32_t* __restrict__ heavy_rows, uint32_t n_heavy,
+                                                        uint32_t nchunks, uint32_t* __restrict__ hcnt) {
   constexpr int SEG = 1024;
-  __shared__ __attribute__((aligned(16))) uint8_t flags[SCW];
+  __shared__ uint32_t bm[BM_WORDS];
   __shared__ uint32_t seg_start[SEG + 1];
   __shared__ uint32_t seg_lo[SEG];
+  __shared__ uint32_t klist[SEG];
   __shared__ uint32_t wsum[17];
-  __shared__ uint32_t ccnt[SC_PER];
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4* f4 = (u32x4*)flags;
-  for (int i = threadIdx.x; i < (int)(SCW / 16); i += 1024) f4[i] = (u32x4)(0u);
-  if (threadIdx.x < SC_PER) ccnt[threadIdx.x] = 0;
+  __shared__ uint32_t ccnt[BM_CHUNKS];
+  for (int i = threadIdx.x; i < BM_WORDS; i += 1024) bm[i] = 0;
+  if (threadIdx.x < BM_CHUNKS) ccnt[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint32_t hrow = item / nsc, sc = item % nsc;
+  const uint32_t nwin = (nchunks + BM_CHUNKS - 1) / BM_CHUNKS;
+  for (uint32_t hrow = blockIdx.x; hrow < n_heavy; hrow += gridDim.x) {
     const uint32_t row = heavy_rows[hrow];
-    const uint32_t c0 = sc << SCW_SHIFT;
-    const uint32_t j0 = sc * SC_PER, j1 = (j0 + SC_PER < nchunks) ? j0 + SC_PER : nchunks;
     const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
-    for (uint64_t pb = ps; pb < pe; pb += SEG) {
-      const uint64_t p = pb + threadIdx.x;
-      uint32_t lo = 0, len = 0;
-      if (p < pe) {
-        const uint32_t k = a_col[p];
-        if (USE_BPOS) {
-          lo = bpos[(uint64_t)j0 * rows_b + k];
-          len = bpos[(uint64_t)j1 * rows_b + k] - lo;
-        } else {
-          lo = (uint32_t)b_rp[k];
-          len = (uint32_t)b_rp[k + 1] - lo;
-        }
-      }
-      const uint32_t st = block_excl_scan_1024(len, wsum);
-      seg_start[threadIdx.x] = st;
-      seg_lo[threadIdx.x] = lo;
-      __syncthreads();
-      const uint32_t total = wsum[16];
-      if (threadIdx.x == 0) seg_start[SEG] = total;
-      __syncthreads();
-      for (uint32_t base = threadIdx.x * HEAVY_U; base < total; base += 1024 * HEAVY_U) {
-        uint32_t sg = seg_find(seg_start, SEG, base);
-        uint32_t cols[HEAVY_U];
-#pragma unroll
-        for (int j = 0; j < HEAVY_U; ++j) {
-          const uint32_t idx = base + j;
-          cols[j] = 0xFFFFFFFFu;
-          if (idx < total) {
-            while (idx >= seg_start[sg + 1]) ++sg;
-            cols[j] = b_col[seg_lo[sg] + (idx - seg_start[sg])];
+    const bool cached = (pe - ps) <= SEG;
+    if (cached && ps + threadIdx.x < pe) klist[threadIdx.x] = a_col[ps + threadIdx.x];
+    __syncthreads();
+    for (uint32_t win = 0; win < nwin; ++win) {
+      const uint32_t j0 = win * BM_CHUNKS, j1 = (j0 + BM_CHUNKS < nchunks) ? j0 + BM_CHUNKS : nchunks;
+      const uint32_t c0 = win << BM_SHIFT;
+      for (uint64_t pb = ps; pb < pe; pb += SEG) {
+        const uint64_t p = pb + threadIdx.x;
+        uint32_t lo = 0, len = 0;
+        if (p < pe) {
+          const uint32_t k = cached ? klist[threadIdx.x] : a_col[p];
+          if (USE_BPOS) {
+            lo = bpos[(uint64_t)j0 * rows_b + k];
+            len = bpos[(uint64_t)j1 * rows_b + k] - lo;
+          } else {
+            lo = (uint32_t)b_rp[k];
+            len = (uint32_t)b_rp[k + 1] - lo;
           }
         }
+        const uint32_t st = block_excl_scan_1024(len, wsum);
+        seg_start[threadIdx.x] = st;
+        seg_lo[threadIdx.x] = lo;
+        __syncthreads();
+        const uint32_t total = wsum[16];
+        if (threadIdx.x == 0) seg_start[SEG] = total;
+        __syncthreads();
+        // each wavefront takes 64*HEAVY_U consecutive products per round, lane-contiguous inside every load
+        for (uint32_t wb = (threadIdx.x >> 6) * (64 * HEAVY_U); wb < total; wb += 1024 * HEAVY_U) {
+          const uint32_t idx0 = wb + (threadIdx.x & 63);
+          uint32_t sg = seg_find(seg_start, SEG, idx0 < total ? idx0 : total - 1);
+          uint32_t cols[HEAVY_U];
 #pragma unroll
-        for (int j = 0; j < HEAVY_U; ++j) {
-          const uint32_t c = cols[j] - c0;
-          if (cols[j] != 0xFFFFFFFFu && c < SCW) flags[c] = 1;
+          for (int j = 0; j < HEAVY_U; ++j) {
+            const uint32_t idx = idx0 + j * 64;
+            cols[j] = 0xFFFFFFFFu;
+            if (idx < total) {
+              sg = seg_advance(seg_start, SEG, sg, idx);
+              cols[j] = b_col[seg_lo[sg] + (idx - seg_start[sg])];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < HEAVY_U; ++j) {
+            const uint32_t c = cols[j] - c0;
+            if (cols[j] != 0xFFFFFFFFu && c < (1u << BM_SHIFT)) atomicOr(&bm[c >> 5], 1u << (c & 31));
+          }
         }
+        __syncthreads();
+      }
+      // popcount per numeric chunk (512 words each); the bitmap is reset on the way
+#pragma unroll 4
+      for (int i = 0; i < BM_WORDS / 1024; ++i) {
+        const uint32_t v = bm[i * 1024 + threadIdx.x];
+        if (v) bm[i * 1024 + threadIdx.x] = 0;
+        const uint32_t n = wave_sum_u32(__popc(v));
+        if ((threadIdx.x & 63) == 0 && n) atomicAdd(&ccnt[2 * i + (threadIdx.x >> 9)], n);
+      }
+      __syncthreads();
+      if (threadIdx.x < BM_CHUNKS) {
+        if (j0 + threadIdx.x < j1) hcnt[(uint64_t)hrow * nchunks + j0 + threadIdx.x] = ccnt[threadIdx.x];
+        ccnt[threadIdx.x] = 0;
       }
       __syncthreads();
     }
-    // iteration i covers exactly numeric chunk j0 + i: 1024 threads x 16 flags = CW; flags are reset here
-#pragma unroll
-    for (int i = 0; i < SC_PER; ++i) {
-      const u32x4 w = f4[i * 1024 + threadIdx.x];
-      uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
-      if (n) f4[i * 1024 + threadIdx.x] = (u32x4)(0u);
-      n = wave_sum_u32(n);
-      if ((threadIdx.x & 63) == 0 && n) atomicAdd(&ccnt[i], n);
-    }
-    __syncthreads();
-    if (threadIdx.x < SC_PER) {
-      if (j0 + threadIdx.x < nchunks) hcnt[(uint64_t)hrow * nchunks + j0 + threadIdx.x] = ccnt[threadIdx.x];
-      ccnt[threadIdx.x] = 0;
-    }
-    __syncthreads();
   }
 }
 
@@ -365,22 +390,6 @@ __global__ __launch_bounds__(256) void heavy_finalize_kernel(const uint32_t* __r
     run += __shfl(inc, 63, 64);
   }
   if (lane == 0) row_nnz[heavy_rows[h]] = run;
-}
-
-// list of non-empty (heavy row, chunk) items for the numeric pass
-__global__ __launch_bounds__(256) void heavy_items_kernel(const uint32_t* __restrict__ num_heavy_rows, uint32_t n_rows,
-                                                         const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks,
-                                                         const uint32_t* __restrict__ hcnt,
-                                                         unsigned long long* __restrict__ n_items,
-                                                         uint64_t* __restrict__ items) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (uint64_t)n_rows * nchunks) return;
-  const uint32_t r = num_heavy_rows[i / nchunks], c = (uint32_t)(i % nchunks);
-  const uint32_t h = hrow_of_row[r];
-  if (hcnt[(uint64_t)h * nchunks + c]) {
-    const unsigned long long pos = atomicAdd(n_items, 1ull);
-    items[pos] = ((uint64_t)h << 32) | c;
-  }
 }
 
 // ---- L5: numeric, hash bins (mul_hash.rs:106-201) ----------------------------------------------------
@@ -468,103 +477,248 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void num_hash_kernel(
   }
 }
 
-// Workgroups loop over the non-empty (heavy row, numeric chunk) items: dense accumulator over CW columns in
-// LDS (LDS float atomics), byte flags for the pattern, compaction in column order (so heavy rows are sorted).
-template <class T, bool USE_BPOS>
+// Numeric pass for heavy rows: one workgroup per row.  The row's numeric chunks are grouped on the fly:
+//   * a chunk holding more than HWIN entries (>12 % dense) is accumulated DENSELY: T acc[CW] + byte flags,
+//     LDS float atomics, compaction in column order;
+//   * runs of sparser chunks are merged while their entries stay below HCAP and share one linprobe table
+//     of HTSIZE slots laid over the same LDS (keys u32 + values T), compaction in slot order.
+// Either way a group writes a contiguous, precomputed piece of C's row (hoff), groups are in increasing
+// column order, and every touched LDS slot is reset while it is read out.
+constexpr uint32_t HWIN = 2048;    // grouping window / dense threshold (entries)
+constexpr uint32_t HCAP = 4096;    // a hash group holds fewer than HCAP entries (load < 0.5)
+constexpr uint32_t HTSIZE = 8192;  // slots
+constexpr uint32_t MAX_HEAVY_CHUNKS = 1024;
+
+template <class T, bool USE_BPOS, bool SORT>
 __global__ __launch_bounds__(1024) void num_heavy_kernel(
     const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
     const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col, const T* __restrict__ b_val,
-    const uint32_t* __restrict__ bpos, uint32_t rows_b, const uint32_t* __restrict__ heavy_rows,
-    const uint64_t* __restrict__ items, uint32_t n_items, uint32_t nchunks, const uint32_t* __restrict__ hoff,
-    const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ c_col, T* __restrict__ c_val) {
-  constexpr int SEG = 512;
+    const uint32_t* __restrict__ bpos, uint32_t rows_b, const uint32_t* __restrict__ rows_list, uint32_t n_rows,
+    const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks, const uint32_t* __restrict__ hcnt,
+    const uint32_t* __restrict__ hoff, const uint32_t* __restrict__ row_nnz, const uint64_t* __restrict__ c_rp,
+    uint32_t* __restrict__ c_col, T* __restrict__ c_val, int dbg) {
+  constexpr int SEG = 256;
   __shared__ __attribute__((aligned(16))) T acc[CW];
   __shared__ __attribute__((aligned(16))) uint8_t flags[CW];
   __shared__ uint32_t seg_start[SEG + 1];
   __shared__ uint32_t seg_lo[SEG];
   __shared__ T seg_av[SEG];
+  __shared__ uint32_t klist[SEG];
+  __shared__ T kval[SEG];
   __shared__ uint32_t wsum[17];
+  __shared__ uint16_t gbeg[MAX_HEAVY_CHUNKS + 1];
+  __shared__ uint32_t goff[MAX_HEAVY_CHUNKS + 1];
+  __shared__ uint32_t ng_s;
+  static_assert(sizeof(T) * CW >= HTSIZE * (4 + sizeof(T)), "hash table must fit the dense accumulator's LDS");
+  static_assert(HCAP == 2 * HWIN && HTSIZE >= 2 * HCAP, "a group of non-dense chunks sharing a window holds < HCAP entries");
+  uint32_t* hkeys = (uint32_t*)acc;
+  T* hvals = (T*)((char*)acc + HTSIZE * 4);
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4* f4 = (u32x4*)flags;
+  u32x4* a4 = (u32x4*)acc;
   f4[threadIdx.x] = (u32x4)(0u);  // 1024 x 16 = CW flags
-  for (int i = threadIdx.x; i < (int)CW; i += 1024) acc[i] = T(0);
+  for (int i = threadIdx.x; i < (int)(sizeof(T) * CW / 16); i += 1024) a4[i] = (u32x4)(0u);
+  int mode = 0;  // 0: acc region all zero (dense-clean); 1: hkeys all EMPTY, hvals zero (hash-clean)
   __syncthreads();
-  for (uint32_t ii = blockIdx.x; ii < n_items; ii += gridDim.x) {
-    const uint64_t it = items[ii];
-    const uint32_t hrow = (uint32_t)(it >> 32), chunk = (uint32_t)it;
-    const uint32_t row = heavy_rows[hrow];
-    const uint32_t c0 = chunk << CW_SHIFT;
+  for (uint32_t ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {
+    const uint32_t row = rows_list[ri];
+    const uint32_t hrow = hrow_of_row[row];
     const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
-    for (uint64_t pb = ps; pb < pe; pb += SEG) {
-      const uint64_t p = pb + threadIdx.x;
-      uint32_t lo = 0, len = 0;
-      if (threadIdx.x < SEG && p < pe) {
-        const uint32_t k = a_col[p];
-        seg_av[threadIdx.x] = a_val[p];
-        if (USE_BPOS) {
-          lo = bpos[(uint64_t)chunk * rows_b + k];
-          len = bpos[(uint64_t)(chunk + 1) * rows_b + k] - lo;
-        } else {
-          lo = (uint32_t)b_rp[k];
-          len = (uint32_t)b_rp[k + 1] - lo;
+    const uint64_t out_row = c_rp[row];
+    const uint32_t* hc = hcnt + (uint64_t)hrow * nchunks;
+    const uint32_t* ho = hoff + (uint64_t)hrow * nchunks;
+    const bool cached = (pe - ps) <= SEG;
+    if (cached && threadIdx.x < SEG && ps + threadIdx.x < pe) {
+      klist[threadIdx.x] = a_col[ps + threadIdx.x];
+      kval[threadIdx.x] = a_val[ps + threadIdx.x];
+    }
+    // group starts: chunk j opens a group if it or its predecessor is dense, or its offset enters a new window
+    {
+      uint32_t startflag = 0, myoff = 0;
+      const uint32_t j = threadIdx.x;
+      if (j < nchunks) {
+        myoff = ho[j];
+        const bool dj = hc[j] > HWIN;
+        if (j == 0)
+          startflag = 1;
+        else
+          startflag = dj || (hc[j - 1] > HWIN) || (myoff / HWIN != ho[j - 1] / HWIN);
+      }
+      const uint32_t pos = block_excl_scan_1024(startflag, wsum);
+      if (startflag) {
+        gbeg[pos] = (uint16_t)j;
+        goff[pos] = myoff;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const uint32_t ng = wsum[16];
+        ng_s = ng;
+        gbeg[ng] = (uint16_t)nchunks;
+        goff[ng] = row_nnz[row];
+      }
+      __syncthreads();
+    }
+    const uint32_t ng = ng_s;
+    for (uint32_t g = 0; g < ng; ++g) {
+      const uint32_t j0 = gbeg[g], j1 = gbeg[g + 1];
+      const uint32_t off0 = goff[g], cnt = goff[g + 1] - off0;
+      if (cnt == 0) continue;
+      const bool dense = (j1 == j0 + 1) && cnt > HWIN;
+      const uint32_t c0 = j0 << CW_SHIFT, cspan = (j1 - j0) << CW_SHIFT;
+      // make the LDS region clean for this group's mode
+      if (dense && mode == 1) {
+        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += 1024) a4[i] = (u32x4)(0u);
+        mode = 0;
+        __syncthreads();
+      } else if (!dense && mode == 0) {
+        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += 1024) a4[i] = (u32x4)(EMPTY_KEY);
+        mode = 1;
+        __syncthreads();
+      }
+      for (uint64_t pb = ps; pb < pe; pb += SEG) {
+        const uint64_t p = pb + threadIdx.x;
+        uint32_t lo = 0, len = 0;
+        if (threadIdx.x < SEG && p < pe) {
+          uint32_t k;
+          if (cached) {
+            k = klist[threadIdx.x];
+            seg_av[threadIdx.x] = kval[threadIdx.x];
+          } else {
+            k = a_col[p];
+            seg_av[threadIdx.x] = a_val[p];
+          }
+          if (dbg & 4) {
+            lo = k, len = 0;
+          } else if (USE_BPOS) {
+            lo = bpos[(uint64_t)j0 * rows_b + k];
+            len = bpos[(uint64_t)j1 * rows_b + k] - lo;
+          } else {
+            lo = (uint32_t)b_rp[k];
+            len = (uint32_t)b_rp[k + 1] - lo;
+          }
+          if (dbg & 1) len = 0;
         }
-      }
-      const uint32_t st = block_excl_scan_1024(len, wsum);
-      if (threadIdx.x < SEG) {
-        seg_start[threadIdx.x] = st;
-        seg_lo[threadIdx.x] = lo;
-      }
-      __syncthreads();
-      const uint32_t total = wsum[16];
-      if (threadIdx.x == 0) seg_start[SEG] = total;
-      __syncthreads();
-      for (uint32_t base = threadIdx.x * HEAVY_U; base < total; base += 1024 * HEAVY_U) {
-        uint32_t sg = seg_find(seg_start, SEG, base);
-        uint32_t cols[HEAVY_U];
-        T prods[HEAVY_U];
+        const uint32_t st = block_excl_scan_1024(len, wsum);
+        if (threadIdx.x < SEG) {
+          seg_start[threadIdx.x] = st;
+          seg_lo[threadIdx.x] = lo;
+        }
+        __syncthreads();
+        const uint32_t total = wsum[16];
+        if (threadIdx.x == 0) seg_start[SEG] = total;
+        __syncthreads();
+        for (uint32_t wb = (threadIdx.x >> 6) * (64 * HEAVY_U); wb < total; wb += 1024 * HEAVY_U) {
+          const uint32_t idx0 = wb + (threadIdx.x & 63);
+          uint32_t sg = seg_find(seg_start, SEG, idx0 < total ? idx0 : total - 1);
+          uint32_t cols[HEAVY_U];
+          T prods[HEAVY_U];
 #pragma unroll
-        for (int j = 0; j < HEAVY_U; ++j) {
-          const uint32_t idx = base + j;
-          cols[j] = 0xFFFFFFFFu;
-          prods[j] = T(0);
-          if (idx < total) {
-            while (idx >= seg_start[sg + 1]) ++sg;
-            const uint32_t q = seg_lo[sg] + (idx - seg_start[sg]);
-            cols[j] = b_col[q];
-            prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
+          for (int j = 0; j < HEAVY_U; ++j) {
+            const uint32_t idx = idx0 + j * 64;
+            cols[j] = 0xFFFFFFFFu;
+            prods[j] = T(0);
+            if (idx < total) {
+              sg = seg_advance(seg_start, SEG, sg, idx);
+              const uint32_t q = seg_lo[sg] + (idx - seg_start[sg]);
+              cols[j] = b_col[q];
+              prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < HEAVY_U; ++j) {
+            const uint32_t c = cols[j] - c0;
+            if (cols[j] != 0xFFFFFFFFu && c < cspan) {
+              if (dense) {
+                atomicAdd(&acc[c], prods[j]);
+                flags[c] = 1;
+              } else {
+                lds_map_upsert<T>(hkeys, hvals, HTSIZE - 1, cols[j], prods[j]);
+              }
+            }
           }
         }
+        __syncthreads();
+      }
+      uint64_t out = out_row + off0;
+      if (dbg & 2) {
+        __syncthreads();
+        continue;
+      }
+      if (dense) {
+        // column order: thread t owns columns [16 t, 16 t + 16)
+        const u32x4 w = f4[threadIdx.x];
+        const uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+        const uint32_t ex = block_excl_scan_1024(n, wsum);
+        if (n) {
+          out += ex;
+          f4[threadIdx.x] = (u32x4)(0u);
+          const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (int j = 0; j < HEAVY_U; ++j) {
-          const uint32_t c = cols[j] - c0;
-          if (cols[j] != 0xFFFFFFFFu && c < CW) {
-            atomicAdd(&acc[c], prods[j]);
-            flags[c] = 1;
+          for (int j = 0; j < 16; ++j) {
+            if ((ww[j >> 2] >> ((j & 3) * 8)) & 1u) {
+              const uint32_t c = threadIdx.x * 16 + j;
+              c_col[out] = c0 + c;
+              c_val[out] = acc[c];
+              acc[c] = T(0);
+              ++out;
+            }
+          }
+        }
+      } else if (SORT) {
+        // B2 = true (mul_hash.rs:164-175): bitonic sort of the whole table by key (u32::MAX = empty sorts
+        // last), after which the group's entries are slots [0, cnt)
+        for (uint32_t k = 2; k <= HTSIZE; k <<= 1) {
+          for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < HTSIZE; i += 1024) {
+              const uint32_t l = i ^ j;
+              if (l > i) {
+                const uint32_t ki = hkeys[i], kl = hkeys[l];
+                if ((ki > kl) == ((i & k) == 0)) {
+                  hkeys[i] = kl;
+                  hkeys[l] = ki;
+                  const T t = hvals[i];
+                  hvals[i] = hvals[l];
+                  hvals[l] = t;
+                }
+              }
+            }
+            __syncthreads();
+          }
+        }
+        for (uint32_t i = threadIdx.x; i < cnt; i += 1024) {
+          c_col[out + i] = hkeys[i];
+          c_val[out + i] = hvals[i];
+          hkeys[i] = EMPTY_KEY;
+          hvals[i] = T(0);
+        }
+      } else {
+        // slot order (map.rs:59-63): thread t owns slots [8 t, 8 t + 8)
+        constexpr int SPT = HTSIZE / 1024;
+        uint32_t kk[SPT];
+        uint32_t n = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+          kk[j] = hkeys[threadIdx.x * SPT + j];
+          n += kk[j] != EMPTY_KEY;
+        }
+        const uint32_t ex = block_excl_scan_1024(n, wsum);
+        if (n) {
+          out += ex;
+#pragma unroll
+          for (int j = 0; j < SPT; ++j) {
+            if (kk[j] != EMPTY_KEY) {
+              const uint32_t slot = threadIdx.x * SPT + j;
+              c_col[out] = kk[j];
+              c_val[out] = hvals[slot];
+              hkeys[slot] = EMPTY_KEY;
+              hvals[slot] = T(0);
+              ++out;
+            }
           }
         }
       }
       __syncthreads();
     }
-    // compaction in column order: thread t owns columns [16 t, 16 t + 16); touched slots are reset here
-    const u32x4 w = f4[threadIdx.x];
-    const uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
-    const uint32_t ex = block_excl_scan_1024(n, wsum);
-    if (n) {
-      uint64_t out = c_rp[row] + hoff[(uint64_t)hrow * nchunks + chunk] + ex;
-      f4[threadIdx.x] = (u32x4)(0u);
-      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if ((ww[j >> 2] >> ((j & 3) * 8)) & 1u) {
-          const uint32_t c = threadIdx.x * 16 + j;
-          c_col[out] = c0 + c;
-          c_val[out] = acc[c];
-          acc[c] = T(0);
-          ++out;
-        }
-      }
-    }
-    __syncthreads();
   }
 }
 
@@ -627,7 +781,7 @@ struct spam_spgemm_plan {
   spam::DevBuf hrow_of_row;  // u32[rows]: index into heavy_rows
   spam::DevBuf hcnt, hoff;   // u32[n_heavy * nchunks]
   spam::DevBuf bpos;         // u32[(nchunks + 1) * rows_b]
-  uint32_t n_heavy = 0, nchunks = 0, nsc = 0;
+  uint32_t n_heavy = 0, nchunks = 0;
   bool use_bpos = false;
   spam_spgemm_stats st{};
   hipEvent_t ev[6] = {};
@@ -755,10 +909,10 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
   // heavy rows: dense flags per symbolic chunk
   p->n_heavy = hc[NSYM - 1];
   p->nchunks = (uint32_t)((b->cols + CW - 1) >> CW_SHIFT);
-  p->nsc = (uint32_t)((b->cols + SCW - 1) >> SCW_SHIFT);
   if (p->n_heavy) {
-    if ((uint64_t)p->n_heavy * p->nsc >= (1ull << 31))
-      return set_error(SPAM_E_UNSUPPORTED, "too many heavy (row, chunk) items for one launch");
+    if (p->nchunks > MAX_HEAVY_CHUNKS)
+      return set_error(SPAM_E_UNSUPPORTED, "rows with more than 4096 intermediate products need cols(B) <= %u",
+                       MAX_HEAVY_CHUNKS * CW);
     SPAM_TRY(p->heavy_rows.alloc((uint64_t)p->n_heavy * 4));
     SPAM_HIP_TRY(hipMemcpyAsync(p->heavy_rows.p, L + (uint64_t)(NSYM - 1) * rows, (uint64_t)p->n_heavy * 4,
                                 hipMemcpyDeviceToDevice, s));
@@ -773,16 +927,15 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     }
     SPAM_TRY(p->hcnt.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
     SPAM_TRY(p->hoff.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
-    const uint32_t n_sym_items = p->n_heavy * p->nsc;
-    const unsigned grid = std::min<uint32_t>(n_sym_items, HEAVY_GRID);  // gridDim.x * 1024 must stay below 2^32
+    const unsigned grid = std::min<uint32_t>(p->n_heavy, HEAVY_GRID);  // gridDim.x * 1024 must stay below 2^32
     if (p->use_bpos)
       sym_heavy_kernel<true><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, p->bpos.as<uint32_t>(),
-                                                   (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), n_sym_items, p->nsc,
-                                                   p->nchunks, p->hcnt.as<uint32_t>());
+                                                   (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
+                                                   p->hcnt.as<uint32_t>());
     else
       sym_heavy_kernel<false><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, nullptr,
-                                                    (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), n_sym_items, p->nsc,
-                                                    p->nchunks, p->hcnt.as<uint32_t>());
+                                                    (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
+                                                    p->hcnt.as<uint32_t>());
     SPAM_CHECK_LAUNCH();
     heavy_finalize_kernel<<<(p->n_heavy + 3) / 4, 256, 0, s>>>(p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
                                                               p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn);
@@ -845,36 +998,23 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
 
   const uint32_t n_hnum = hc[NNUM - 1];
   if (n_hnum) {
-    // non-empty (row, chunk) items
-    const uint64_t cand = (uint64_t)n_hnum * p->nchunks;
-    DevBuf items;
-    SPAM_TRY(items.alloc(cand * 8));
-    unsigned long long* d_nitems = (unsigned long long*)(counts.as<uint32_t>() + 8);
-    heavy_items_kernel<<<(unsigned)((cand + 255) / 256), 256, 0, s>>>(L + (uint64_t)(NNUM - 1) * rows, n_hnum,
-                                                                       p->hrow_of_row.as<uint32_t>(), p->nchunks,
-                                                                       p->hcnt.as<uint32_t>(), d_nitems,
-                                                                       items.as<uint64_t>());
-    SPAM_CHECK_LAUNCH();
-    unsigned long long n_items = 0;
-    SPAM_HIP_TRY(hipMemcpyAsync(&n_items, d_nitems, 8, hipMemcpyDeviceToHost, s));
-    SPAM_HIP_TRY(hipStreamSynchronize(s));
-    st.heavy_items = n_items;
-    if (n_items >= (1ull << 31)) return set_error(SPAM_E_UNSUPPORTED, "too many heavy (row, chunk) items for one launch");
-    if (n_items) {
-      const unsigned hgrid = (unsigned)std::min<unsigned long long>(n_items, HEAVY_GRID);
-      if (p->use_bpos)
-        num_heavy_kernel<T, true><<<hgrid, 1024, 0, s>>>(
-            a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals, p->bpos.as<uint32_t>(),
-            (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), items.as<uint64_t>(), (uint32_t)n_items, p->nchunks,
-            p->hoff.as<uint32_t>(), crp, cc, cv);
-      else
-        num_heavy_kernel<T, false><<<hgrid, 1024, 0, s>>>(
-            a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals, nullptr,
-            (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), items.as<uint64_t>(), (uint32_t)n_items, p->nchunks,
-            p->hoff.as<uint32_t>(), crp, cc, cv);
-      SPAM_CHECK_LAUNCH();
+    const unsigned hgrid = std::min<uint32_t>(n_hnum, HEAVY_GRID);
+    const char* dbg_env = getenv("SPAM_DBG_HEAVY");  // timing ablations only (results are wrong when set)
+    const int dbg_heavy = dbg_env ? atoi(dbg_env) : 0;
+    const uint32_t* hl = L + (uint64_t)(NNUM - 1) * rows;
+#define SPAM_NUM_HEAVY(BPOS_, SORT_)                                                                             \
+  num_heavy_kernel<T, BPOS_, SORT_><<<hgrid, 1024, 0, s>>>(                                                      \
+      a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals,                      \
+      BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, hl, n_hnum, p->hrow_of_row.as<uint32_t>(),    \
+      p->nchunks, p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn, crp, cc, cv, dbg_heavy)
+    if (p->use_bpos) {
+      if (sort_rows) SPAM_NUM_HEAVY(true, true); else SPAM_NUM_HEAVY(true, false);
+    } else {
+      if (sort_rows) SPAM_NUM_HEAVY(false, true); else SPAM_NUM_HEAVY(false, false);
     }
-    SPAM_HIP_TRY(hipStreamSynchronize(s));  // items is freed at scope exit
+#undef SPAM_NUM_HEAVY
+    SPAM_CHECK_LAUNCH();
+    st.heavy_items = n_hnum;
   }
   if (sort_rows) {
     SPAM_TRY((launch_sort<T, 16, 64>(L + 0ull * rows, hc[0], crp, cc, cv, s)));

@@ -18,6 +18,7 @@
 //     second tiny kernel — deterministic, no float atomics.
 //   The row -> tile map (first row starting in each tile) depends on row_ptr only and is built once per
 //   matrix (the analysis step of CSR-adaptive), then reused by every SpMV on that handle.
+#include <algorithm>
 #include <cstdlib>
 
 #include "spam_internal.hpp"
@@ -29,14 +30,27 @@ struct SpmvPlan {
   void* carry = nullptr;            // T[ntiles]
   uint64_t ntiles = 0;
   int npt = 0;                      // nnz per thread the map was built for
+  // hot-column table (analysis): the hot_k most referenced columns get slots in a small dense table xh
+  // that stays L2-resident; ja_hot[p] = HOT_BIT | slot for those, the plain column otherwise.
+  int hot_kb = -1;                  // table budget the analysis ran for (-1: not analysed)
+  uint32_t hot_k = 0;               // 0: disabled (x fits L2 anyway, or the hot set covers too little)
+  double hot_cover = 0.0;           // fraction of nnz whose column is hot
+  uint32_t* ja_hot = nullptr;       // u32[nnz]
+  uint32_t* hot_cols = nullptr;     // u32[hot_k]
+  void* xh = nullptr;               // T[hot_k], rebuilt from x by every SpMV
 };
 
 void spmv_plan_free(SpmvPlan* p) {
   if (!p) return;
   if (p->first_owned) dev_free(p->first_owned);
   if (p->carry) dev_free(p->carry);
+  if (p->ja_hot) dev_free(p->ja_hot);
+  if (p->hot_cols) dev_free(p->hot_cols);
+  if (p->xh) dev_free(p->xh);
   delete p;
 }
+
+constexpr uint32_t HOT_BIT = 0x80000000u;
 
 constexpr int SPMV_TPB = 256;
 constexpr int SHORT_ROW = 32;
@@ -85,12 +99,27 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
-template <class T, class OffT, int NPT, bool NT>
+// HOT: 0 = col holds plain column indices; 1 = col is ja_hot, one load with a per-lane base (xh or x);
+//      2 = col is ja_hot, hot entries from xh, cold entries by a non-temporal load (no L2 allocation).
+template <class T, int HOT>
+__device__ __forceinline__ T gather_x(const T* __restrict__ x, const T* __restrict__ xh, uint32_t c) {
+  if (HOT == 0) return x[c];
+  const uint32_t i = c & ~HOT_BIT;
+  if (HOT == 1) {
+    const T* b = (c & HOT_BIT) ? xh : x;
+    return b[i];
+  }
+  if (c & HOT_BIT) return xh[i];
+  return __builtin_nontemporal_load(x + i);
+}
+
+template <class T, class OffT, int NPT, bool NT, int HOT>
 __global__ __launch_bounds__(SPMV_TPB) void spmv_tile_kernel(const OffT* __restrict__ row_ptr,
                                                             const uint32_t* __restrict__ col,
                                                             const T* __restrict__ val, const T* __restrict__ x,
-                                                            T* __restrict__ y, const uint32_t* __restrict__ fo,
-                                                            T* __restrict__ carry, uint64_t nnz) {
+                                                            const T* __restrict__ xh, T* __restrict__ y,
+                                                            const uint32_t* __restrict__ fo, T* __restrict__ carry,
+                                                            uint64_t nnz) {
   constexpr int TILE = SPMV_TPB * NPT;
   constexpr int MAXLONG = TILE / (SHORT_ROW + 1) + 2;
   __shared__ T prod[TILE + TILE / 32 + 1];
@@ -126,7 +155,7 @@ __global__ __launch_bounds__(SPMV_TPB) void spmv_tile_kernel(const OffT* __restr
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xv[i][j] = x[c[i][j]];
+      for (int j = 0; j < 4; ++j) xv[i][j] = gather_x<T, HOT>(x, xh, c[i][j]);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -135,7 +164,8 @@ __global__ __launch_bounds__(SPMV_TPB) void spmv_tile_kernel(const OffT* __restr
       for (int j = 0; j < 4; ++j) prod[pad_idx(q + j)] = v[i][j / VN][j % VN] * xv[i][j];
     }
   } else {
-    for (uint32_t q = tid; q < cnt; q += SPMV_TPB) prod[pad_idx(q)] = val[base + q] * x[col[base + q]];
+    for (uint32_t q = tid; q < cnt; q += SPMV_TPB)
+      prod[pad_idx(q)] = val[base + q] * gather_x<T, HOT>(x, xh, col[base + q]);
   }
   __syncthreads();
 
@@ -209,6 +239,124 @@ __global__ void fill_zero_kernel(T* __restrict__ y, uint64_t n) {
   if (i < n) y[i] = T(0);
 }
 
+// ---- hot-column analysis (once per matrix) ----------------------------------------------------------
+__global__ void col_count_kernel(const uint32_t* __restrict__ col, uint64_t nnz, uint32_t* __restrict__ cnt) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) atomicAdd(&cnt[col[i]], 1u);
+}
+// out[0] = #columns with cnt >= t, out[1] = their total count
+__global__ void count_ge_kernel(const uint32_t* __restrict__ cnt, uint32_t cols, uint32_t t,
+                                unsigned long long* __restrict__ out) {
+  unsigned long long n = 0, m = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cols; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = cnt[i];
+    if (c >= t) {
+      n += 1;
+      m += c;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    n += __shfl_xor(n, d, 64);
+    m += __shfl_xor(m, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && n) {
+    atomicAdd(&out[0], n);
+    atomicAdd(&out[1], m);
+  }
+}
+__global__ void hot_flag_kernel(const uint32_t* __restrict__ cnt, uint32_t cols, uint32_t t, uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cols) flag[i] = cnt[i] >= t;
+}
+// slot[c] = HOT_BIT | rank for hot columns, c otherwise; hot_cols[rank] = c
+__global__ void hot_assign_kernel(const uint32_t* __restrict__ flag, const uint64_t* __restrict__ pos, uint32_t cols,
+                                  uint32_t* __restrict__ slot, uint32_t* __restrict__ hot_cols) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cols) return;
+  if (flag[i]) {
+    const uint32_t r = (uint32_t)pos[i];
+    slot[i] = HOT_BIT | r;
+    hot_cols[r] = (uint32_t)i;
+  } else {
+    slot[i] = (uint32_t)i;
+  }
+}
+__global__ void remap_cols_kernel(const uint32_t* __restrict__ col, uint64_t nnz, const uint32_t* __restrict__ slot,
+                                  uint32_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) out[i] = slot[col[i]];
+}
+template <class T>
+__global__ void xh_build_kernel(const T* __restrict__ x, const uint32_t* __restrict__ hot_cols, uint32_t k,
+                                T* __restrict__ xh) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < k) xh[i] = x[hot_cols[i]];
+}
+
+// Decide the hot set: the largest threshold t whose columns {cnt >= t} fit the table budget.  Disabled when x
+// fits the budget anyway, when cols >= 2^31 (no spare bit), or when the hot set covers < 40 % of the gathers.
+template <class T>
+static int spmv_hot_analyse(const spam_csr* a, SpmvPlan* p, int hot_kb, hipStream_t s) {
+  p->hot_kb = hot_kb;
+  p->hot_k = 0;
+  const uint64_t kmax = (uint64_t)hot_kb * 1024 / sizeof(T);
+  if (hot_kb <= 0 || a->cols >= HOT_BIT || a->cols <= 2 * kmax || a->nnz == 0) return SPAM_OK;
+  const uint32_t cols = (uint32_t)a->cols;
+  DevBuf cnt, out, flag, pos, tmp, slot;
+  SPAM_TRY(cnt.alloc((uint64_t)cols * 4));
+  SPAM_TRY(out.alloc(16));
+  SPAM_HIP_TRY(hipMemsetAsync(cnt.p, 0, (uint64_t)cols * 4, s));
+  col_count_kernel<<<8192, 256, 0, s>>>(a->col_idx, a->nnz, cnt.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  // bisect t in [1, 2^31): count(t) is non-increasing; want the smallest t with count(t) <= kmax
+  uint32_t lo = 1, hi = 0x7FFFFFFFu;
+  unsigned long long best[2] = {0, 0};
+  const unsigned g = (unsigned)std::min<uint64_t>((cols + 255) / 256, 4096);
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    unsigned long long h[2];
+    SPAM_HIP_TRY(hipMemsetAsync(out.p, 0, 16, s));
+    count_ge_kernel<<<g, 256, 0, s>>>(cnt.as<uint32_t>(), cols, mid, out.as<unsigned long long>());
+    SPAM_CHECK_LAUNCH();
+    SPAM_HIP_TRY(hipMemcpyAsync(h, out.p, 16, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+    if (h[0] <= kmax) {
+      hi = mid;
+      best[0] = h[0], best[1] = h[1];
+    } else {
+      lo = mid + 1;
+    }
+  }
+  const uint32_t t = lo;
+  if (best[0] == 0 || (double)best[1] < 0.40 * (double)a->nnz) return SPAM_OK;
+  SPAM_TRY(flag.alloc((uint64_t)cols * 4));
+  SPAM_TRY(pos.alloc(((uint64_t)cols + 1) * 8));
+  SPAM_TRY(tmp.alloc(scan_tmp_bytes(cols)));
+  SPAM_TRY(slot.alloc((uint64_t)cols * 4));
+  DevBuf ja, hc, xh;
+  SPAM_TRY(ja.alloc(a->nnz * 4));
+  SPAM_TRY(hc.alloc(best[0] * 4));
+  SPAM_TRY(xh.alloc(best[0] * sizeof(T)));
+  const unsigned gc = (unsigned)((cols + 255) / 256);
+  hot_flag_kernel<<<gc, 256, 0, s>>>(cnt.as<uint32_t>(), cols, t, flag.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  SPAM_TRY(scan_u32_to_u64(flag.as<uint32_t>(), cols, pos.as<uint64_t>(), tmp.p, s));
+  hot_assign_kernel<<<gc, 256, 0, s>>>(flag.as<uint32_t>(), pos.as<uint64_t>(), cols, slot.as<uint32_t>(), hc.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  remap_cols_kernel<<<8192, 256, 0, s>>>(a->col_idx, a->nnz, slot.as<uint32_t>(), ja.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  SPAM_HIP_TRY(hipStreamSynchronize(s));  // temporaries go back to the pool at scope exit
+  p->hot_k = (uint32_t)best[0];
+  p->hot_cover = (double)best[1] / (double)a->nnz;
+  p->ja_hot = (uint32_t*)ja.release();
+  p->hot_cols = (uint32_t*)hc.release();
+  p->xh = xh.release();
+  return SPAM_OK;
+}
+
 static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
@@ -222,7 +370,7 @@ static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, 
     return SPAM_OK;
   }
   const int npt_cfg = env_int("SPAM_SPMV_NPT", 16);  // read per call so one process can A/B variants
-  const int nt_cfg = env_int("SPAM_SPMV_NT", 0);
+  const int nt_cfg = env_int("SPAM_SPMV_NT", 1);  // non-temporal ja/a stream: keeps L2 for x (+4..6 % on random gathers)
   const int npt = (npt_cfg == 8) ? 8 : 16;
   const uint32_t tile = SPMV_TPB * npt;
   spam_csr* am = const_cast<spam_csr*>(a);
@@ -253,19 +401,43 @@ static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, 
     }
     am->spmv_plan = p;
   }
+  const int hot_cfg = env_int("SPAM_SPMV_HOT", 2);        // 0 off, 1 per-lane base select, 2 cold gathers non-temporal
+  const int hot_kb = hot_cfg ? env_int("SPAM_SPMV_HOT_KB", 3072) : 0;  // of the 4 MB L2 per XCD
+  if (am->spmv_plan->hot_kb != hot_kb) {
+    SpmvPlan* pm = am->spmv_plan;
+    if (pm->ja_hot) dev_free(pm->ja_hot);
+    if (pm->hot_cols) dev_free(pm->hot_cols);
+    if (pm->xh) dev_free(pm->xh);
+    pm->ja_hot = pm->hot_cols = nullptr;
+    pm->xh = nullptr;
+    SPAM_TRY(spmv_hot_analyse<T>(a, pm, hot_kb, s));
+  }
   const SpmvPlan* p = a->spmv_plan;
   const unsigned grid = (unsigned)p->ntiles;
-  const uint32_t* col = a->col_idx;
+  const int hot = p->hot_k ? hot_cfg : 0;
+  const uint32_t* col = hot ? p->ja_hot : a->col_idx;
   const T* val = (const T*)a->vals;
+  const T* xh = (const T*)p->xh;
   T* carry = (T*)p->carry;
-#define SPAM_LAUNCH_TILE(NPT_, NT_)                                                                             \
-  spmv_tile_kernel<T, OffT, NPT_, NT_><<<grid, SPMV_TPB, 0, s>>>(row_ptr, col, val, x, y, p->first_owned, carry, \
-                                                                  a->nnz)
-  if (npt == 8) {
-    if (nt_cfg) SPAM_LAUNCH_TILE(8, true); else SPAM_LAUNCH_TILE(8, false);
-  } else {
-    if (nt_cfg) SPAM_LAUNCH_TILE(16, true); else SPAM_LAUNCH_TILE(16, false);
+  if (hot) {
+    xh_build_kernel<T><<<(p->hot_k + 255) / 256, 256, 0, s>>>(x, p->hot_cols, p->hot_k, (T*)p->xh);
+    SPAM_CHECK_LAUNCH();
   }
+#define SPAM_LAUNCH_TILE(NPT_, NT_, HOT_)                                                                          \
+  spmv_tile_kernel<T, OffT, NPT_, NT_, HOT_><<<grid, SPMV_TPB, 0, s>>>(row_ptr, col, val, x, xh, y, p->first_owned, \
+                                                                        carry, a->nnz)
+#define SPAM_LAUNCH_HOT(NPT_, NT_)             \
+  do {                                         \
+    if (hot == 0) SPAM_LAUNCH_TILE(NPT_, NT_, 0); \
+    else if (hot == 1) SPAM_LAUNCH_TILE(NPT_, NT_, 1); \
+    else SPAM_LAUNCH_TILE(NPT_, NT_, 2);       \
+  } while (0)
+  if (npt == 8) {
+    if (nt_cfg) SPAM_LAUNCH_HOT(8, true); else SPAM_LAUNCH_HOT(8, false);
+  } else {
+    if (nt_cfg) SPAM_LAUNCH_HOT(16, true); else SPAM_LAUNCH_HOT(16, false);
+  }
+#undef SPAM_LAUNCH_HOT
 #undef SPAM_LAUNCH_TILE
   SPAM_CHECK_LAUNCH();
   if (p->ntiles > 1) {

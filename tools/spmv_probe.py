@@ -24,7 +24,7 @@ def main():
     vs = A.vals.element_size()
     nbytes = A.nnz * (vs + 4) + (A.rows + 1) * 4 + A.cols * vs + A.rows * vs
     print(which, A.stats(), "alg bytes %.3f GB" % (nbytes / 1e9), flush=True)
-    variants = [dict(SPAM_SPMV_NPT=n, SPAM_SPMV_NT=t) for n in (16, 8) for t in (0, 1)]
+    variants = [dict(SPAM_SPMV_HOT=h, SPAM_SPMV_NT=t) for h in (2, 0) for t in (1, 0)]
     extra = os.environ.get("PROBE_VARIANTS")
     if extra:
         variants = json.loads(extra)
