@@ -53,6 +53,8 @@ typedef struct spam_spgemm_stats {
   uint64_t rows_sym_bin[8];        /* rows per symbolic bin (by F)   */
   uint64_t rows_num_bin[8];        /* rows per numeric bin (by nnz)  */
   uint64_t heavy_items;            /* rows on the heavy (chunked LDS accumulator) numeric path */
+  uint64_t heavy_dense_groups, heavy_hash_groups; /* their column-chunk groups by accumulator kind */
+  uint64_t heavy_dense_nnz, heavy_hash_nnz;       /* entries of C produced by each kind */
   float ms_flops, ms_symbolic, ms_alloc, ms_numeric, ms_total; /* device time, HIP events on the library stream */
 } spam_spgemm_stats;
 

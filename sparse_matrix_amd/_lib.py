@@ -31,6 +31,8 @@ class SpgemmStats(C.Structure):
                 ("flops_f", C.c_uint64),
                 ("rows_sym_bin", C.c_uint64 * 8), ("rows_num_bin", C.c_uint64 * 8),
                 ("heavy_items", C.c_uint64),
+                ("heavy_dense_groups", C.c_uint64), ("heavy_hash_groups", C.c_uint64),
+                ("heavy_dense_nnz", C.c_uint64), ("heavy_hash_nnz", C.c_uint64),
                 ("ms_flops", C.c_float), ("ms_symbolic", C.c_float), ("ms_alloc", C.c_float),
                 ("ms_numeric", C.c_float), ("ms_total", C.c_float)]
 

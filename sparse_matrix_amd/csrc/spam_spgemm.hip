@@ -142,9 +142,11 @@ __device__ __forceinline__ bool lds_set_insert(uint32_t* table, uint32_t mask, u
 }
 // linprobe::HashMap::entry + and_modify/or_insert (map.rs:67-120; mul_hash.rs:157-161).  Values start at 0,
 // so "first product stored" and "+= product" are the same atomic add.
-template <class T>
+// FIB = true replaces linprobe's multiplier 107 (which maps columns c and c + size to the same slot; R-MAT rows
+// hold many such pairs and linear probing then degenerates into long runs) by Fibonacci hashing on the top bits.
+template <class T, bool FIB = false>
 __device__ __forceinline__ void lds_map_upsert(uint32_t* keys, T* vals, uint32_t mask, uint32_t key, T v) {
-  uint32_t h = (key * HASH_SCAL) & mask;
+  uint32_t h = FIB ? ((key * 0x9E3779B1u) >> (__clz(mask))) & mask : (key * HASH_SCAL) & mask;
   for (;;) {
     const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, key);
     if (old == EMPTY_KEY || old == key) {
@@ -152,6 +154,67 @@ __device__ __forceinline__ void lds_map_upsert(uint32_t* keys, T* vals, uint32_t
       return;
     }
     h = (h + 1) & mask;
+  }
+}
+
+template <int U>
+__device__ __forceinline__ uint32_t lds_set_insert_batch(uint32_t* table, uint32_t mask, const uint32_t (&k)[U]) {
+  uint32_t h[U], old[U], added = 0;
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    h[j] = (k[j] * HASH_SCAL) & mask;
+    old[j] = k[j] != EMPTY_KEY ? atomicCAS(&table[h[j]], EMPTY_KEY, k[j]) : k[j];
+  }
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    if (k[j] != EMPTY_KEY) {
+      if (old[j] == EMPTY_KEY) {
+        ++added;
+      } else if (old[j] != k[j]) {
+        uint32_t hh = (h[j] + 1) & mask;
+        for (;;) {
+          const uint32_t o = atomicCAS(&table[hh], EMPTY_KEY, k[j]);
+          if (o == EMPTY_KEY) {
+            ++added;
+            break;
+          }
+          if (o == k[j]) break;
+          hh = (hh + 1) & mask;
+        }
+      }
+    }
+  }
+  return added;
+}
+
+// First probe of U independent upserts issued back to back (one LDS round trip for all of them); only the
+// keys whose home slot holds another key fall back to the sequential probe loop.
+template <class T, int U, bool FIB>
+__device__ __forceinline__ void lds_map_upsert_batch(uint32_t* keys, T* vals, uint32_t mask, const uint32_t (&k)[U],
+                                                     const T (&v)[U], const bool (&ok)[U]) {
+  uint32_t h[U], old[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    h[j] = FIB ? ((k[j] * 0x9E3779B1u) >> (__clz(mask))) & mask : (k[j] * HASH_SCAL) & mask;
+    old[j] = ok[j] ? atomicCAS(&keys[h[j]], EMPTY_KEY, k[j]) : k[j];
+  }
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    if (ok[j]) {
+      if (old[j] == EMPTY_KEY || old[j] == k[j]) {
+        atomicAdd(&vals[h[j]], v[j]);
+      } else {
+        uint32_t hh = (h[j] + 1) & mask;
+        for (;;) {
+          const uint32_t o = atomicCAS(&keys[hh], EMPTY_KEY, k[j]);
+          if (o == EMPTY_KEY || o == k[j]) {
+            atomicAdd(&vals[hh], v[j]);
+            break;
+          }
+          hh = (hh + 1) & mask;
+        }
+      }
+    }
   }
 }
 
@@ -192,28 +255,6 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void sym_hash_kernel(
   if (valid && gl == 0) row_nnz[row] = cnt[g];  // *row_nz = hs.len() (mul_hash.rs:95)
 }
 
-// ---- heavy rows: B rows pre-split at numeric-chunk boundaries ---------------------------------------
-// bpos[j * rows_b + k] = first position q in B's row k with col[q] >= j * CW, j = 0..nchunks (absolute, u32).
-__global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
-                                                  uint32_t rows_b, uint32_t nchunks, uint32_t* __restrict__ bpos) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t k = wave; k < rows_b; k += nwaves) {
-    const uint64_t s = b_rp[k], e = b_rp[k + 1];
-    for (uint64_t q = s + lane; q < e; q += 64) {
-      const uint32_t cq = b_col[q] >> CW_SHIFT;
-      const uint32_t cp = (q == s) ? 0u : (b_col[q - 1] >> CW_SHIFT);
-      for (uint32_t j = cp + 1; j <= cq; ++j) bpos[(uint64_t)j * rows_b + k] = (uint32_t)q;
-    }
-    if (lane == 0) {
-      bpos[k] = (uint32_t)s;
-      const uint32_t cl = (e > s) ? (b_col[e - 1] >> CW_SHIFT) : 0u;
-      for (uint32_t j = cl + 1; j <= nchunks; ++j) bpos[(uint64_t)j * rows_b + k] = (uint32_t)e;
-    }
-  }
-}
-
 // ---- flattened product space for the heavy kernels ---------------------------------------------------
 // A batch of up to SEG entries k of A's row gives SEG segments [lo_s, lo_s + len_s) of B's arrays.  Their
 // lengths are prefix-summed into LDS (seg_start) and the workgroup then walks the concatenated product
@@ -221,6 +262,30 @@ __global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ 
 // walk over segment boundaries), so lanes stay busy whatever the mix of short and long B rows, and each
 // lane has HEAVY_U independent loads in flight.
 constexpr int HEAVY_U = 8;
+
+template <int TPB>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /* [TPB/64 + 1] */) {
+  constexpr int NW = TPB / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();  // wsum may still be read from the previous call
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const uint32_t c = wsum[i];
+    if (i < w) off += c;
+    tot += c;
+  }
+  if (threadIdx.x == 0) wsum[NW] = tot;
+  return off + inc - v;
+}
 
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wsum /* [17] */) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -273,6 +338,179 @@ __device__ __forceinline__ uint32_t seg_advance(const uint32_t* seg_start, uint3
       hi = mid;
   }
   return lo;
+}
+
+// ---- one row per workgroup, flattened product space (mid-size rows) -----------------------------------
+// Same traversal as the heavy kernels (segments = whole B rows, prefix sum in LDS, each wavefront takes
+// 64*ROW_U consecutive products per round so every load is lane-contiguous), linprobe table in LDS.
+constexpr int ROW_U = 8;
+
+template <int TPB, int TABLE>
+__global__ __launch_bounds__(TPB) void sym_row_kernel(const uint64_t* __restrict__ a_rp,
+                                                     const uint32_t* __restrict__ a_col,
+                                                     const uint64_t* __restrict__ b_rp,
+                                                     const uint32_t* __restrict__ b_col,
+                                                     const uint64_t* __restrict__ flops,
+                                                     const uint32_t* __restrict__ rows_list, uint32_t nrows,
+                                                     uint32_t* __restrict__ row_nnz) {
+  constexpr int SEG = TPB;
+  __shared__ uint32_t table[TABLE];
+  __shared__ uint32_t seg_start[SEG + 1];
+  __shared__ uint32_t seg_lo[SEG];
+  __shared__ uint32_t wsum[TPB / 64 + 1];
+  __shared__ uint32_t cnt;
+  for (uint32_t ri = blockIdx.x; ri < nrows; ri += gridDim.x) {
+    const uint32_t row = rows_list[ri];
+    const uint64_t f = flops[row];
+    const uint32_t tsize = table_size_for((uint32_t)(f > TABLE / 2 ? TABLE / 2 : f));  // hs.shrink_to (mul_hash.rs:87)
+    const uint32_t mask = tsize - 1;
+    for (uint32_t i = threadIdx.x; i < tsize; i += TPB) table[i] = EMPTY_KEY;
+    if (threadIdx.x == 0) cnt = 0;
+    uint32_t mine = 0;
+    const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
+    for (uint64_t pb = ps; pb < pe; pb += SEG) {
+      const uint64_t p = pb + threadIdx.x;
+      uint32_t lo = 0, len = 0;
+      if (p < pe) {
+        const uint32_t k = a_col[p];
+        lo = (uint32_t)b_rp[k];
+        len = (uint32_t)b_rp[k + 1] - lo;
+      }
+      const uint32_t st = block_excl_scan<TPB>(len, wsum);
+      seg_start[threadIdx.x] = st;
+      seg_lo[threadIdx.x] = lo;
+      __syncthreads();
+      const uint32_t total = wsum[TPB / 64];
+      if (threadIdx.x == 0) seg_start[SEG] = total;
+      __syncthreads();
+      const uint32_t upl = total >= TPB * ROW_U ? ROW_U : (total + TPB - 1) / TPB;  // spread small rows over all waves
+      for (uint32_t wb = (threadIdx.x >> 6) * (64 * upl); wb < total; wb += TPB * upl) {
+        const uint32_t idx0 = wb + (threadIdx.x & 63);
+        uint32_t sg = seg_find(seg_start, SEG, idx0 < total ? idx0 : total - 1);
+        uint32_t cols[ROW_U];
+#pragma unroll
+        for (int j = 0; j < ROW_U; ++j) {
+          const uint32_t idx = idx0 + j * 64;
+          cols[j] = EMPTY_KEY;
+          if (j < upl && idx < total) {
+            sg = seg_advance(seg_start, SEG, sg, idx);
+            cols[j] = b_col[seg_lo[sg] + (idx - seg_start[sg])];
+          }
+        }
+        mine += lds_set_insert_batch<ROW_U>(table, mask, cols);
+      }
+      __syncthreads();
+    }
+    mine = wave_sum_u32(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) row_nnz[row] = cnt;  // *row_nz = hs.len() (mul_hash.rs:95)
+    __syncthreads();
+  }
+}
+
+template <class T, int TPB, int TABLE>
+__global__ __launch_bounds__(TPB) void num_row_kernel(
+    const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
+    const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col, const T* __restrict__ b_val,
+    const uint32_t* __restrict__ rows_list, uint32_t nrows, const uint32_t* __restrict__ row_nnz,
+    const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ c_col, T* __restrict__ c_val) {
+  constexpr int SEG = TPB;
+  __shared__ uint32_t keys[TABLE];
+  __shared__ T vals[TABLE];
+  __shared__ uint32_t seg_start[SEG + 1];
+  __shared__ uint32_t seg_lo[SEG];
+  __shared__ T seg_av[SEG];
+  __shared__ uint32_t wsum[TPB / 64 + 1];
+  for (uint32_t ri = blockIdx.x; ri < nrows; ri += gridDim.x) {
+    const uint32_t row = rows_list[ri];
+    const uint32_t tsize = table_size_for(row_nnz[row]);  // hm.shrink_to(*row_nz) (mul_hash.rs:144)
+    const uint32_t mask = tsize - 1;
+    for (uint32_t i = threadIdx.x; i < tsize; i += TPB) {
+      keys[i] = EMPTY_KEY;
+      vals[i] = T(0);
+    }
+    const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
+    for (uint64_t pb = ps; pb < pe; pb += SEG) {
+      const uint64_t p = pb + threadIdx.x;
+      uint32_t lo = 0, len = 0;
+      if (p < pe) {
+        const uint32_t k = a_col[p];
+        seg_av[threadIdx.x] = a_val[p];
+        lo = (uint32_t)b_rp[k];
+        len = (uint32_t)b_rp[k + 1] - lo;
+      }
+      const uint32_t st = block_excl_scan<TPB>(len, wsum);
+      seg_start[threadIdx.x] = st;
+      seg_lo[threadIdx.x] = lo;
+      __syncthreads();
+      const uint32_t total = wsum[TPB / 64];
+      if (threadIdx.x == 0) seg_start[SEG] = total;
+      __syncthreads();
+      const uint32_t upl = total >= TPB * ROW_U ? ROW_U : (total + TPB - 1) / TPB;  // spread small rows over all waves
+      for (uint32_t wb = (threadIdx.x >> 6) * (64 * upl); wb < total; wb += TPB * upl) {
+        const uint32_t idx0 = wb + (threadIdx.x & 63);
+        uint32_t sg = seg_find(seg_start, SEG, idx0 < total ? idx0 : total - 1);
+        uint32_t cols[ROW_U];
+        T prods[ROW_U];
+#pragma unroll
+        for (int j = 0; j < ROW_U; ++j) {
+          const uint32_t idx = idx0 + j * 64;
+          cols[j] = EMPTY_KEY;
+          prods[j] = T(0);
+          if (j < upl && idx < total) {
+            sg = seg_advance(seg_start, SEG, sg, idx);
+            const uint32_t q = seg_lo[sg] + (idx - seg_start[sg]);
+            cols[j] = b_col[q];
+            prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
+          }
+        }
+        bool okv[ROW_U];
+#pragma unroll
+        for (int j = 0; j < ROW_U; ++j) okv[j] = cols[j] != EMPTY_KEY;
+        lds_map_upsert_batch<T, ROW_U, false>(keys, vals, mask, cols, prods, okv);
+      }
+      __syncthreads();
+    }
+    // drain in slot order (map.rs:59-63): thread t owns slots [t*spt, (t+1)*spt)
+    const uint32_t spt = tsize / TPB;  // >= 1: this bin has tsize >= TPB
+    uint32_t n = 0;
+    for (uint32_t j = 0; j < spt; ++j) n += keys[threadIdx.x * spt + j] != EMPTY_KEY;
+    const uint32_t ex = block_excl_scan<TPB>(n, wsum);
+    uint64_t out = c_rp[row] + ex;
+    for (uint32_t j = 0; j < spt; ++j) {
+      const uint32_t slot = threadIdx.x * spt + j;
+      const uint32_t k = keys[slot];
+      if (k != EMPTY_KEY) {
+        c_col[out] = k;
+        c_val[out] = vals[slot];
+        ++out;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- heavy rows: B rows pre-split at numeric-chunk boundaries ---------------------------------------
+// bpos[j * rows_b + k] = first position q in B's row k with col[q] >= j * CW, j = 0..nchunks (absolute, u32).
+__global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
+                                                  uint32_t rows_b, uint32_t nchunks, uint32_t* __restrict__ bpos) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t k = wave; k < rows_b; k += nwaves) {
+    const uint64_t s = b_rp[k], e = b_rp[k + 1];
+    for (uint64_t q = s + lane; q < e; q += 64) {
+      const uint32_t cq = b_col[q] >> CW_SHIFT;
+      const uint32_t cp = (q == s) ? 0u : (b_col[q - 1] >> CW_SHIFT);
+      for (uint32_t j = cp + 1; j <= cq; ++j) bpos[(uint64_t)j * rows_b + k] = (uint32_t)q;
+    }
+    if (lane == 0) {
+      bpos[k] = (uint32_t)s;
+      const uint32_t cl = (e > s) ? (b_col[e - 1] >> CW_SHIFT) : 0u;
+      for (uint32_t j = cl + 1; j <= nchunks; ++j) bpos[(uint64_t)j * rows_b + k] = (uint32_t)e;
+    }
+  }
 }
 
 // Symbolic pass for heavy rows: one workgroup per row, a 2^20-column bitmap window in LDS (LDS atomic OR),
@@ -496,7 +734,7 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
     const uint32_t* __restrict__ bpos, uint32_t rows_b, const uint32_t* __restrict__ rows_list, uint32_t n_rows,
     const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks, const uint32_t* __restrict__ hcnt,
     const uint32_t* __restrict__ hoff, const uint32_t* __restrict__ row_nnz, const uint64_t* __restrict__ c_rp,
-    uint32_t* __restrict__ c_col, T* __restrict__ c_val, int dbg) {
+    uint32_t* __restrict__ c_col, T* __restrict__ c_val, unsigned long long* __restrict__ gstats, int dbg) {
   constexpr int SEG = 256;
   __shared__ __attribute__((aligned(16))) T acc[CW];
   __shared__ __attribute__((aligned(16))) uint8_t flags[CW];
@@ -520,7 +758,10 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
   for (int i = threadIdx.x; i < (int)(sizeof(T) * CW / 16); i += 1024) a4[i] = (u32x4)(0u);
   int mode = 0;  // 0: acc region all zero (dense-clean); 1: hkeys all EMPTY, hvals zero (hash-clean)
   __syncthreads();
+  unsigned long long t_row = 0, t_a = 0, t_p = 0, t_c = 0, t_da = 0, t_dp = 0, t_dc = 0, t0 = 0, t1 = 0;
+  const bool timing = (dbg & 32) && threadIdx.x == 0;
   for (uint32_t ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {
+    if (timing) t0 = clock64();
     const uint32_t row = rows_list[ri];
     const uint32_t hrow = hrow_of_row[row];
     const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
@@ -559,12 +800,21 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
       __syncthreads();
     }
     const uint32_t ng = ng_s;
+    if (timing) {
+      t1 = clock64();
+      t_row += t1 - t0;
+    }
     for (uint32_t g = 0; g < ng; ++g) {
+      if (timing) t0 = clock64();
       const uint32_t j0 = gbeg[g], j1 = gbeg[g + 1];
       const uint32_t off0 = goff[g], cnt = goff[g + 1] - off0;
       if (cnt == 0) continue;
       const bool dense = (j1 == j0 + 1) && cnt > HWIN;
       const uint32_t c0 = j0 << CW_SHIFT, cspan = (j1 - j0) << CW_SHIFT;
+      if (threadIdx.x == 0) {  // group census for spam_spgemm_stats
+        atomicAdd(&gstats[dense ? 0 : 1], 1ull);
+        atomicAdd(&gstats[dense ? 2 : 3], (unsigned long long)cnt);
+      }
       // make the LDS region clean for this group's mode
       if (dense && mode == 1) {
         for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += 1024) a4[i] = (u32x4)(0u);
@@ -607,7 +857,15 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
         const uint32_t total = wsum[16];
         if (threadIdx.x == 0) seg_start[SEG] = total;
         __syncthreads();
-        for (uint32_t wb = (threadIdx.x >> 6) * (64 * HEAVY_U); wb < total; wb += 1024 * HEAVY_U) {
+        if (timing) {
+          t1 = clock64();
+          (dense ? t_da : t_a) += t1 - t0;
+          t0 = t1;
+        }
+        // products per lane and round: HEAVY_U when there is enough work, fewer when the group is small so that
+        // all 16 wavefronts share it (the chain of LDS round trips per lane is what a small group waits for)
+        const uint32_t upl = total >= 1024 * HEAVY_U ? HEAVY_U : (total + 1023) / 1024;
+        for (uint32_t wb = (threadIdx.x >> 6) * (64 * upl); wb < total; wb += 1024 * upl) {
           const uint32_t idx0 = wb + (threadIdx.x & 63);
           uint32_t sg = seg_find(seg_start, SEG, idx0 < total ? idx0 : total - 1);
           uint32_t cols[HEAVY_U];
@@ -617,32 +875,46 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
             const uint32_t idx = idx0 + j * 64;
             cols[j] = 0xFFFFFFFFu;
             prods[j] = T(0);
-            if (idx < total) {
+            if (j < upl && idx < total) {
               sg = seg_advance(seg_start, SEG, sg, idx);
               const uint32_t q = seg_lo[sg] + (idx - seg_start[sg]);
-              cols[j] = b_col[q];
-              prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < HEAVY_U; ++j) {
-            const uint32_t c = cols[j] - c0;
-            if (cols[j] != 0xFFFFFFFFu && c < cspan) {
-              if (dense) {
-                atomicAdd(&acc[c], prods[j]);
-                flags[c] = 1;
+              if (dbg & 16) {  // timing ablation: no product loads
+                cols[j] = c0 + (idx % (cnt < cspan ? cnt : cspan));
+                prods[j] = seg_av[sg];
               } else {
-                lds_map_upsert<T>(hkeys, hvals, HTSIZE - 1, cols[j], prods[j]);
+                cols[j] = b_col[q];
+                prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
               }
             }
+          }
+          if (dbg & 8) {  // timing ablation: loads only
+#pragma unroll
+            for (int j = 0; j < HEAVY_U; ++j) asm volatile("" ::"v"(cols[j]), "v"(prods[j]));
+            continue;
+          }
+          bool okv[HEAVY_U];
+#pragma unroll
+          for (int j = 0; j < HEAVY_U; ++j) okv[j] = cols[j] != 0xFFFFFFFFu && (cols[j] - c0) < cspan;
+          if (dense) {
+#pragma unroll
+            for (int j = 0; j < HEAVY_U; ++j) {
+              if (okv[j]) {
+                const uint32_t c = cols[j] - c0;
+                atomicAdd(&acc[c], prods[j]);
+                flags[c] = 1;
+              }
+            }
+          } else {
+            lds_map_upsert_batch<T, HEAVY_U, true>(hkeys, hvals, HTSIZE - 1, cols, prods, okv);
           }
         }
         __syncthreads();
       }
       uint64_t out = out_row + off0;
-      if (dbg & 2) {
-        __syncthreads();
-        continue;
+      if (timing) {
+        t1 = clock64();
+        (dense ? t_dp : t_p) += t1 - t0;
+        t0 = t1;
       }
       if (dense) {
         // column order: thread t owns columns [16 t, 16 t + 16)
@@ -718,7 +990,20 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
         }
       }
       __syncthreads();
+      if (timing) {
+        t1 = clock64();
+        (dense ? t_dc : t_c) += t1 - t0;
+      }
     }
+  }
+  if (timing) {
+    atomicAdd(&gstats[4], t_row);
+    atomicAdd(&gstats[5], t_a);
+    atomicAdd(&gstats[6], t_p);
+    atomicAdd(&gstats[7], t_c);
+    atomicAdd(&gstats[8], t_da);
+    atomicAdd(&gstats[9], t_dp);
+    atomicAdd(&gstats[10], t_dc);
   }
 }
 
@@ -814,6 +1099,8 @@ static int check_pair(const spam_csr* a, const spam_csr* b) {
                      "(mul_hash.rs:46)",
                      (unsigned long long)a->cols, (unsigned long long)b->rows);
   if (a->dtype != b->dtype) return set_error(SPAM_E_DTYPE, "A and B have different value types");
+  if (b->nnz >= (1ull << 32))
+    return set_error(SPAM_E_UNSUPPORTED, "nnz(B) >= 2^32: the SpGEMM kernels keep 32-bit positions into B's arrays");
   return SPAM_OK;
 }
 
@@ -838,6 +1125,27 @@ static int launch_num_hash(const spam_csr* a, const spam_csr* b, const uint32_t*
   num_hash_kernel<T, G, S, TABLE><<<(n + RPW - 1) / RPW, TPB, 0, s>>>(a->row_ptr, a->col_idx, (const T*)a->vals,
                                                                        b->row_ptr, b->col_idx, (const T*)b->vals, list,
                                                                        n, row_nnz, c_rp, c_col, c_val);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+template <int TPB, int TABLE>
+static int launch_sym_row(const spam_csr* a, const spam_csr* b, const uint64_t* flops, const uint32_t* list, uint32_t n,
+                          uint32_t* row_nnz, hipStream_t s) {
+  if (!n) return SPAM_OK;
+  sym_row_kernel<TPB, TABLE><<<std::min<uint32_t>(n, 16384), TPB, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx,
+                                                                        flops, list, n, row_nnz);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+template <class T, int TPB, int TABLE>
+static int launch_num_row(const spam_csr* a, const spam_csr* b, const uint32_t* list, uint32_t n,
+                          const uint32_t* row_nnz, const uint64_t* c_rp, uint32_t* c_col, T* c_val, hipStream_t s) {
+  if (!n) return SPAM_OK;
+  num_row_kernel<T, TPB, TABLE><<<std::min<uint32_t>(n, 16384), TPB, 0, s>>>(
+      a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals, list, n, row_nnz, c_rp,
+      c_col, c_val);
   SPAM_CHECK_LAUNCH();
   return SPAM_OK;
 }
@@ -904,7 +1212,7 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
   const uint64_t* fl = p->flops.as<uint64_t>();
   SPAM_TRY((launch_sym_hash<16, 4, 128>(a, b, fl, L + 0ull * rows, hc[0], rn, s)));
   SPAM_TRY((launch_sym_hash<64, 8, 1024>(a, b, fl, L + 1ull * rows, hc[1], rn, s)));
-  SPAM_TRY((launch_sym_hash<256, 16, 8192>(a, b, fl, L + 2ull * rows, hc[2], rn, s)));
+  SPAM_TRY((launch_sym_row<256, 8192>(a, b, fl, L + 2ull * rows, hc[2], rn, s)));
 
   // heavy rows: dense flags per symbolic chunk
   p->n_heavy = hc[NSYM - 1];
@@ -916,8 +1224,6 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     SPAM_TRY(p->heavy_rows.alloc((uint64_t)p->n_heavy * 4));
     SPAM_HIP_TRY(hipMemcpyAsync(p->heavy_rows.p, L + (uint64_t)(NSYM - 1) * rows, (uint64_t)p->n_heavy * 4,
                                 hipMemcpyDeviceToDevice, s));
-    if (b->nnz >= (1ull << 32))
-      return set_error(SPAM_E_UNSUPPORTED, "rows with more than 4096 intermediate products need nnz(B) < 2^32");
     p->use_bpos = b->is_sorted && p->nchunks > 1;
     if (p->use_bpos) {
       SPAM_TRY(p->bpos.alloc((uint64_t)(p->nchunks + 1) * b->rows * 4));
@@ -993,8 +1299,8 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
   T* cv = cval.as<T>();
   SPAM_TRY((launch_num_hash<T, 16, 4, 128>(a, b, L + 0ull * rows, hc[0], rn, crp, cc, cv, s)));
   SPAM_TRY((launch_num_hash<T, 64, 8, 1024>(a, b, L + 1ull * rows, hc[1], rn, crp, cc, cv, s)));
-  SPAM_TRY((launch_num_hash<T, 256, 16, 4096>(a, b, L + 2ull * rows, hc[2], rn, crp, cc, cv, s)));
-  SPAM_TRY((launch_num_hash<T, 1024, 16, 8192>(a, b, L + 3ull * rows, hc[3], rn, crp, cc, cv, s)));
+  SPAM_TRY((launch_num_row<T, 256, 4096>(a, b, L + 2ull * rows, hc[2], rn, crp, cc, cv, s)));
+  SPAM_TRY((launch_num_row<T, 1024, 8192>(a, b, L + 3ull * rows, hc[3], rn, crp, cc, cv, s)));
 
   const uint32_t n_hnum = hc[NNUM - 1];
   if (n_hnum) {
@@ -1002,11 +1308,15 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     const char* dbg_env = getenv("SPAM_DBG_HEAVY");  // timing ablations only (results are wrong when set)
     const int dbg_heavy = dbg_env ? atoi(dbg_env) : 0;
     const uint32_t* hl = L + (uint64_t)(NNUM - 1) * rows;
+    DevBuf gst;
+    SPAM_TRY(gst.alloc(128));
+    SPAM_HIP_TRY(hipMemsetAsync(gst.p, 0, 128, s));
 #define SPAM_NUM_HEAVY(BPOS_, SORT_)                                                                             \
   num_heavy_kernel<T, BPOS_, SORT_><<<hgrid, 1024, 0, s>>>(                                                      \
       a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals,                      \
       BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, hl, n_hnum, p->hrow_of_row.as<uint32_t>(),    \
-      p->nchunks, p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn, crp, cc, cv, dbg_heavy)
+      p->nchunks, p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn, crp, cc, cv, gst.as<unsigned long long>(),  \
+      dbg_heavy)
     if (p->use_bpos) {
       if (sort_rows) SPAM_NUM_HEAVY(true, true); else SPAM_NUM_HEAVY(true, false);
     } else {
@@ -1015,6 +1325,13 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
 #undef SPAM_NUM_HEAVY
     SPAM_CHECK_LAUNCH();
     st.heavy_items = n_hnum;
+    unsigned long long hg[16];
+    SPAM_HIP_TRY(hipMemcpyAsync(hg, gst.p, 128, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+    if (dbg_heavy & 32)
+      fprintf(stderr, "[spam dbg] heavy phase cycles (sum over workgroups): row-setup %llu  groupA %llu  products %llu  compaction %llu  (dense: A %llu prod %llu comp %llu)\n",
+              hg[4], hg[5], hg[6], hg[7], hg[8], hg[9], hg[10]);
+    st.heavy_dense_groups = hg[0], st.heavy_hash_groups = hg[1], st.heavy_dense_nnz = hg[2], st.heavy_hash_nnz = hg[3];
   }
   if (sort_rows) {
     SPAM_TRY((launch_sort<T, 16, 64>(L + 0ull * rows, hc[0], crp, cc, cv, s)));

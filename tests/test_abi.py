@@ -65,5 +65,5 @@ def test_status_codes_match_header():
 def test_stats_struct_layout_matches_header():
     from sparse_matrix_amd._lib import SpgemmStats
 
-    # 7 + 8 + 8 + 1 u64, then 5 floats (+4 bytes tail padding)
-    assert C.sizeof(SpgemmStats) == (7 + 16 + 1) * 8 + 5 * 4 + 4
+    # 7 + 8 + 8 + 1 + 4 u64, then 5 floats (+4 bytes tail padding)
+    assert C.sizeof(SpgemmStats) == (7 + 16 + 1 + 4) * 8 + 5 * 4 + 4

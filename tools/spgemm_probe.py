@@ -19,7 +19,7 @@ def main():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         C, st = dA.spgemm(dA, sort_rows=bool(sort_rows))
         torch.cuda.synchronize(); t = time.perf_counter() - t0
-        if r == reps - 1:
+        if r == reps - 1 and not os.environ.get('SPAM_DBG_HEAVY'):
             # size-independent property: C*1 == A*(A*1) row by row (uses the SpMV kernel on C and on A)
             ones = torch.ones(A.cols, dtype=torch.float64, device=dev)
             t1 = torch.empty(A.rows, dtype=torch.float64, device=dev); t2 = torch.empty_like(t1); t3 = torch.empty_like(t1)
@@ -41,6 +41,7 @@ def main():
         print(f"rep {r}: wall {t*1e3:.1f} ms  F={st['flops_f']:.3e} nnzC={st['nnz_c']:.3e}  "
               f"flops {st['ms_flops']:.2f} sym {st['ms_symbolic']:.2f} alloc {st['ms_alloc']:.2f} num {st['ms_numeric']:.2f} ms  "
               f"-> {st['flops_f']/t/1e9:.1f} Gprod/s {st['nnz_c']/t/1e6:.0f} Mnnz/s", flush=True)
+    print("heavy groups: dense", st["heavy_dense_groups"], "nnz", st["heavy_dense_nnz"], " hash", st["heavy_hash_groups"], "nnz", st["heavy_hash_nnz"])
     print("sym bins", st["rows_sym_bin"][:4], "num bins", st["rows_num_bin"][:5], "heavy items", st["heavy_items"])
 
 main()
