@@ -196,7 +196,8 @@ def main():
             rp, col, val = spdist.allgather_csr(blk.row_ptr, blk.col_idx, blk.vals, n, rank, world, dist)
             B = DeviceCsr.from_torch(n, n, rp, col, val, True)
             if world > 1:
-                _, offs = B.rows_to_parts(B, world)  # rows_to_threads with tnum = world (mul_hash.rs:38-64)
+                flops, _ = B.rows_to_parts(B, world)  # rows_to_threads' flop count (mul_hash.rs:39-50)
+                offs = spdist.balanced_row_blocks(flops.astype(np.int64), world)  # its partition rule on F + row cost
                 mylo, myhi = int(offs[rank]), int(offs[rank + 1])
                 if myhi <= mylo:
                     return None, None

@@ -526,8 +526,10 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
                                                         const uint32_t* __restrict__ b_col,
                                                         const uint32_t* __restrict__ bpos, uint32_t rows_b,
                                                         const uint32_t* __restrict__ heavy_rows, uint32_t n_heavy,
-                                                        uint32_t nchunks, uint32_t* __restrict__ hcnt) {
+                                                        uint32_t nchunks, uint32_t* __restrict__ hcnt,
+                                                        uint32_t* __restrict__ queue) {
   constexpr int SEG = 1024;
+  __shared__ uint32_t item_s;
   __shared__ uint32_t bm[BM_WORDS];
   __shared__ uint32_t seg_start[SEG + 1];
   __shared__ uint32_t seg_lo[SEG];
@@ -538,7 +540,12 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
   if (threadIdx.x < BM_CHUNKS) ccnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t nwin = (nchunks + BM_CHUNKS - 1) / BM_CHUNKS;
-  for (uint32_t hrow = blockIdx.x; hrow < n_heavy; hrow += gridDim.x) {
+  for (;;) {  // rows from a device-wide queue (their cost varies by three orders of magnitude)
+    __syncthreads();
+    if (threadIdx.x == 0) item_s = atomicAdd(queue, 1u);
+    __syncthreads();
+    const uint32_t hrow = item_s;
+    if (hrow >= n_heavy) break;
     const uint32_t row = heavy_rows[hrow];
     const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
     const bool cached = (pe - ps) <= SEG;
@@ -715,6 +722,19 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void num_hash_kernel(
   }
 }
 
+// rows whose A row is longer than `thr` go to the giant list (processed as several items per row)
+__global__ __launch_bounds__(256) void split_giant_kernel(const uint32_t* __restrict__ list, uint32_t n,
+                                                         const uint64_t* __restrict__ a_rp, uint32_t thr,
+                                                         uint32_t* __restrict__ normal, uint32_t* __restrict__ giant,
+                                                         uint32_t* __restrict__ counts) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = list[i];
+  const bool g = a_rp[r + 1] - a_rp[r] > thr;
+  const uint32_t pos = atomicAdd(&counts[g ? 1 : 0], 1u);
+  (g ? giant : normal)[pos] = r;
+}
+
 // Numeric pass for heavy rows: one workgroup per row.  The row's numeric chunks are grouped on the fly:
 //   * a chunk holding more than HWIN entries (>12 % dense) is accumulated DENSELY: T acc[CW] + byte flags,
 //     LDS float atomics, compaction in column order;
@@ -726,15 +746,18 @@ constexpr uint32_t HWIN = 2048;    // grouping window / dense threshold (entries
 constexpr uint32_t HCAP = 4096;    // a hash group holds fewer than HCAP entries (load < 0.5)
 constexpr uint32_t HTSIZE = 8192;  // slots
 constexpr uint32_t MAX_HEAVY_CHUNKS = 1024;
+constexpr uint32_t GIANT_NNZ_A = 1024;  // A rows longer than this are cut into GIANT_PARTS work items
+constexpr uint32_t GIANT_PARTS = 16;
 
 template <class T, bool USE_BPOS, bool SORT>
 __global__ __launch_bounds__(1024) void num_heavy_kernel(
     const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
     const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col, const T* __restrict__ b_val,
     const uint32_t* __restrict__ bpos, uint32_t rows_b, const uint32_t* __restrict__ rows_list, uint32_t n_rows,
-    const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks, const uint32_t* __restrict__ hcnt,
-    const uint32_t* __restrict__ hoff, const uint32_t* __restrict__ row_nnz, const uint64_t* __restrict__ c_rp,
-    uint32_t* __restrict__ c_col, T* __restrict__ c_val, unsigned long long* __restrict__ gstats, int dbg) {
+    uint32_t parts, uint32_t* __restrict__ queue, const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks,
+    const uint32_t* __restrict__ hcnt, const uint32_t* __restrict__ hoff, const uint32_t* __restrict__ row_nnz,
+    const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ c_col, T* __restrict__ c_val,
+    unsigned long long* __restrict__ gstats, int dbg) {
   constexpr int SEG = 256;
   __shared__ __attribute__((aligned(16))) T acc[CW];
   __shared__ __attribute__((aligned(16))) uint8_t flags[CW];
@@ -746,7 +769,7 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
   __shared__ uint32_t wsum[17];
   __shared__ uint16_t gbeg[MAX_HEAVY_CHUNKS + 1];
   __shared__ uint32_t goff[MAX_HEAVY_CHUNKS + 1];
-  __shared__ uint32_t ng_s;
+  __shared__ uint32_t ng_s, item_s;
   static_assert(sizeof(T) * CW >= HTSIZE * (4 + sizeof(T)), "hash table must fit the dense accumulator's LDS");
   static_assert(HCAP == 2 * HWIN && HTSIZE >= 2 * HCAP, "a group of non-dense chunks sharing a window holds < HCAP entries");
   uint32_t* hkeys = (uint32_t*)acc;
@@ -760,7 +783,17 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
   __syncthreads();
   unsigned long long t_row = 0, t_a = 0, t_p = 0, t_c = 0, t_da = 0, t_dp = 0, t_dc = 0, t0 = 0, t1 = 0;
   const bool timing = (dbg & 32) && threadIdx.x == 0;
-  for (uint32_t ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {
+  // Work items come from a device-wide queue (rows cost anything from 5 k to 10 M products, so a static
+  // split leaves a long tail).  An item is (row, part): rows with a very long A row are cut into `parts`
+  // items that take the row's chunk groups round-robin — groups are independent pieces of the output.
+  const uint32_t n_items = n_rows * parts;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) item_s = atomicAdd(queue, 1u);
+    __syncthreads();
+    const uint32_t item = item_s;
+    if (item >= n_items) break;
+    const uint32_t ri = item / parts, part = item % parts;
     if (timing) t0 = clock64();
     const uint32_t row = rows_list[ri];
     const uint32_t hrow = hrow_of_row[row];
@@ -804,7 +837,7 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
       t1 = clock64();
       t_row += t1 - t0;
     }
-    for (uint32_t g = 0; g < ng; ++g) {
+    for (uint32_t g = part; g < ng; g += parts) {
       if (timing) t0 = clock64();
       const uint32_t j0 = gbeg[g], j1 = gbeg[g + 1];
       const uint32_t off0 = goff[g], cnt = goff[g + 1] - off0;
@@ -1186,11 +1219,11 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
 
   // bin rows by F
   DevBuf counts, lists;
-  SPAM_TRY(counts.alloc(8 * 4));
+  SPAM_TRY(counts.alloc(16 * 4));  // [0..7] bin counts, [8] work queue of sym_heavy_kernel
   SPAM_TRY(lists.alloc((uint64_t)NSYM * rows * 4));
   SPAM_TRY(p->hrow_of_row.alloc((uint64_t)rows * 4));
   SPAM_TRY(p->row_nnz.alloc((uint64_t)rows * 4));
-  SPAM_HIP_TRY(hipMemsetAsync(counts.p, 0, 32, s));
+  SPAM_HIP_TRY(hipMemsetAsync(counts.p, 0, 64, s));
   SPAM_HIP_TRY(hipMemsetAsync(p->row_nnz.p, 0, (uint64_t)rows * 4, s));  // rows with F = 0 are skipped (mul_hash.rs:84)
   BinLimits lim{};
   lim.nbins = NSYM;
@@ -1237,11 +1270,11 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     if (p->use_bpos)
       sym_heavy_kernel<true><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, p->bpos.as<uint32_t>(),
                                                    (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
-                                                   p->hcnt.as<uint32_t>());
+                                                   p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
     else
       sym_heavy_kernel<false><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, nullptr,
                                                     (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
-                                                    p->hcnt.as<uint32_t>());
+                                                    p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
     SPAM_CHECK_LAUNCH();
     heavy_finalize_kernel<<<(p->n_heavy + 3) / 4, 256, 0, s>>>(p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
                                                               p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn);
@@ -1304,24 +1337,38 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
 
   const uint32_t n_hnum = hc[NNUM - 1];
   if (n_hnum) {
-    const unsigned hgrid = std::min<uint32_t>(n_hnum, HEAVY_GRID);
     const char* dbg_env = getenv("SPAM_DBG_HEAVY");  // timing ablations only (results are wrong when set)
     const int dbg_heavy = dbg_env ? atoi(dbg_env) : 0;
     const uint32_t* hl = L + (uint64_t)(NNUM - 1) * rows;
-    DevBuf gst;
-    SPAM_TRY(gst.alloc(128));
-    SPAM_HIP_TRY(hipMemsetAsync(gst.p, 0, 128, s));
-#define SPAM_NUM_HEAVY(BPOS_, SORT_)                                                                             \
-  num_heavy_kernel<T, BPOS_, SORT_><<<hgrid, 1024, 0, s>>>(                                                      \
+    DevBuf gst, split;
+    SPAM_TRY(gst.alloc(256));
+    SPAM_TRY(split.alloc((uint64_t)n_hnum * 8));
+    SPAM_HIP_TRY(hipMemsetAsync(gst.p, 0, 256, s));
+    uint32_t* qcnt = (uint32_t*)(gst.as<unsigned long long>() + 16);  // [0..1] split counts, [2..3] work queues
+    uint32_t* l_normal = split.as<uint32_t>();
+    uint32_t* l_giant = l_normal + n_hnum;
+    split_giant_kernel<<<(n_hnum + 255) / 256, 256, 0, s>>>(hl, n_hnum, a->row_ptr, GIANT_NNZ_A, l_normal, l_giant, qcnt);
+    SPAM_CHECK_LAUNCH();
+    uint32_t hsplit[2];
+    SPAM_HIP_TRY(hipMemcpyAsync(hsplit, qcnt, 8, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+#define SPAM_NUM_HEAVY(BPOS_, SORT_, LIST_, N_, PARTS_, Q_)                                                       \
+  num_heavy_kernel<T, BPOS_, SORT_><<<std::min<uint32_t>((N_) * (PARTS_), HEAVY_GRID), 1024, 0, s>>>(              \
       a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals,                      \
-      BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, hl, n_hnum, p->hrow_of_row.as<uint32_t>(),    \
-      p->nchunks, p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn, crp, cc, cv, gst.as<unsigned long long>(),  \
-      dbg_heavy)
+      BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, LIST_, N_, PARTS_, Q_,                         \
+      p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn, crp, cc, cv, \
+      gst.as<unsigned long long>(), dbg_heavy)
+#define SPAM_NUM_HEAVY_BOTH(BPOS_, SORT_)                                                              \
+  do {                                                                                                 \
+    if (hsplit[1]) SPAM_NUM_HEAVY(BPOS_, SORT_, l_giant, hsplit[1], GIANT_PARTS, qcnt + 2); /* first */ \
+    if (hsplit[0]) SPAM_NUM_HEAVY(BPOS_, SORT_, l_normal, hsplit[0], 1u, qcnt + 3);                     \
+  } while (0)
     if (p->use_bpos) {
-      if (sort_rows) SPAM_NUM_HEAVY(true, true); else SPAM_NUM_HEAVY(true, false);
+      if (sort_rows) SPAM_NUM_HEAVY_BOTH(true, true); else SPAM_NUM_HEAVY_BOTH(true, false);
     } else {
-      if (sort_rows) SPAM_NUM_HEAVY(false, true); else SPAM_NUM_HEAVY(false, false);
+      if (sort_rows) SPAM_NUM_HEAVY_BOTH(false, true); else SPAM_NUM_HEAVY_BOTH(false, false);
     }
+#undef SPAM_NUM_HEAVY_BOTH
 #undef SPAM_NUM_HEAVY
     SPAM_CHECK_LAUNCH();
     st.heavy_items = n_hnum;

@@ -73,3 +73,14 @@ def rows_to_parts_host(row_flops: torch.Tensor, nparts: int) -> list[int]:
         offs.append(pp - 1)
     offs.append(f.numel())
     return offs
+
+
+ROW_OVERHEAD_PRODUCTS = 2300  # measured on MI355X (scale-20 A*A): a non-empty row costs about as much as 2300 products
+
+
+def balanced_row_blocks(row_flops, nparts: int, row_overhead: int = ROW_OVERHEAD_PRODUCTS) -> list[int]:
+    """The reference's partition rule (rows_to_threads, mul_hash.rs:51-62) applied to a cost that adds a fixed
+    per-row term to the intermediate-product count: blocks of many light rows otherwise run ~20 % longer than
+    blocks of few heavy rows with the same F (SURVEY.md §8e "cost-weighted partition")."""
+    f = torch.as_tensor(row_flops).to(torch.int64).cpu()
+    return rows_to_parts_host(f + row_overhead * (f > 0).to(torch.int64), nparts)
