@@ -198,3 +198,22 @@ def test_full_size_row_sum_property(spam):
         rp = C.download_row_ptr().astype(np.int64)
         assert rp[0] == 0 and rp[-1] == st["nnz_c"] and np.all(np.diff(rp) >= 0)
         C.free()
+
+
+def test_matrix_market_bench_shape(spam, oracle, tmp_path):
+    """The reference's bench path end to end (spam_csr/src/lib.rs:389-435): Matrix Market text -> DOK ->
+    CsrMatrix::from (sorted) -> m.mul_hash(&m) unsorted, against the oracle on the same parsed matrix."""
+    from sparse_matrix_amd.mmio import into_float_matrix_market, parse_matrix_market
+
+    m = synth.rmat(8, signed=True)
+    off, idx, val = csr_np(m)
+    ents = {(r, int(idx[p])): float(val[p]) for r in range(m.rows) for p in range(int(off[r]), int(off[r + 1]))}
+    f = tmp_path / "rmat8.mtx"
+    f.write_text(into_float_matrix_market(m.rows, m.cols, ents))
+    kind, rows, cols, back = parse_matrix_market(f.read_text())
+    assert kind == "real" and back == ents
+    A = spam.CsrMatrix.from_dok((rows, cols), back)
+    assert np.array_equal(A.offsets, off) and np.array_equal(A.indices, idx) and np.array_equal(A.vals, val)
+    C = A * A  # impl Mul -> CsrMatrix<T, false>
+    want = oracle.mul_hash((off, idx, val), (off, idx, val), sort_rows=False)
+    assert_csr_parity((C.offsets, C.indices, C.vals), want, False, 1e-9)  # signed data: looser relative bar

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""The reference's bench shape on the GPU path: for every Matrix Market file in a directory, parse it, build
+CsrMatrix::from(dok) (sorted rows) and time m.mul_hash(&m) with unsorted output (gen_bench_mul!,
+spam_csr/src/lib.rs:386-437; benches/mul_hash.rs:6-11 uses ./matrices).  Integer files are run as f64
+(the GPU path serves f32/f64); complex files are skipped.  Prints one JSON line per file.
+
+  python tools/bench_mm.py DIR [--reps 5]
+"""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sparse_matrix_amd import CsrMatrix, _lib
+from sparse_matrix_amd.mmio import parse_matrix_market
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dir")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    _lib.ensure_device()
+    for name in sorted(os.listdir(args.dir)):
+        path = os.path.join(args.dir, name)
+        if not os.path.isfile(path):
+            continue  # entry.file_type()?.is_file() (lib.rs:416)
+        kind, rows, cols, ents = parse_matrix_market(open(path).read())
+        if kind == "complex":
+            print(json.dumps({"file": name, "skipped": "complex values: CPU path only"}))
+            continue
+        m = CsrMatrix.from_dok((rows, cols), ents, dtype=np.float64)
+        d = m.device()
+        ts, st = [], None
+        for _ in range(args.reps + 1):
+            t0 = time.perf_counter()
+            C, st = d.spgemm(d, sort_rows=False)
+            _lib.check(_lib.load().spam_hip_synchronize())
+            ts.append(time.perf_counter() - t0)
+            C.free()
+        t = float(np.median(ts[1:]))
+        print(json.dumps({"file": name, "kind": kind, "rows": rows, "cols": cols, "nnz": m.nnz(), "flops_F": st["flops_f"],
+                          "nnz_c": st["nnz_c"], "ms": round(t * 1e3, 4), "Mnnz_out_per_s": round(st["nnz_c"] / t / 1e6, 2),
+                          "gflops": round(2 * st["flops_f"] / t / 1e9, 3)}))
+
+
+if __name__ == "__main__":
+    main()
