@@ -118,8 +118,14 @@ int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y); /* device-resi
  * spam_spgemm_numeric_* = mul_hash_numeric::<B1, B2> (:106-201); sort_rows is the const generic B2
  *                         (rows sorted by column).  With sort_rows = 0 each row is emitted in this
  *                         library's own table order: the same SET of (col, value) per row as the
- *                         reference, not its linprobe slot order.  Explicit zeros are kept (structure =
- *                         symbolic pattern), as in the reference. */
+ *                         reference, not its linprobe slot order.  sort_rows = 2 (SPAM_ORDER_REFERENCE)
+ *                         reproduces the reference's unsorted output exactly — linprobe slot order,
+ *                         map.rs:59-63 — for products whose rows hold at most 4096 entries, and fails with
+ *                         SPAM_E_UNSUPPORTED otherwise.  Explicit zeros are kept (structure = symbolic
+ *                         pattern), as in the reference. */
+#define SPAM_ORDER_TABLE 0
+#define SPAM_ORDER_SORTED 1
+#define SPAM_ORDER_REFERENCE 2
 int spam_spgemm_symbolic(const spam_csr* a, const spam_csr* b, spam_spgemm_plan** plan, uint64_t* nnz_out);
 int spam_spgemm_numeric_f64(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out /* rows+1 */,
                             uint64_t* indices_out /* nnz */, double* vals_out /* nnz */);

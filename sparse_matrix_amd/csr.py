@@ -120,11 +120,12 @@ class DeviceCsr:
         check(fn(self._h, _vp(x), _vp(y)))
         return y
 
-    def spgemm(self, rhs: "DeviceCsr", sort_rows: bool = False):
-        """C = self * rhs, device-resident.  Returns (DeviceCsr, stats dict)."""
+    def spgemm(self, rhs: "DeviceCsr", sort_rows=False):
+        """C = self * rhs, device-resident.  sort_rows: False/0 table order, True/1 sorted (B2), 2 the
+        reference's linprobe slot order.  Returns (DeviceCsr, stats dict)."""
         h = C.c_void_p()
         st = SpgemmStats()
-        check(_lib.load().spam_spgemm_dev(self._h, rhs._h, int(bool(sort_rows)), C.byref(h), C.byref(st)))
+        check(_lib.load().spam_spgemm_dev(self._h, rhs._h, int(sort_rows), C.byref(h), C.byref(st)))
         return DeviceCsr(h), st.asdict()
 
     def rows_to_parts(self, rhs: "DeviceCsr", nparts: int):
@@ -242,8 +243,10 @@ class CsrMatrix:
         return self._dev
 
     # -- the hot path ------------------------------------------------------------------------
-    def mul_hash(self, rhs: "CsrMatrix", sort_output: bool = False) -> "CsrMatrix":
+    def mul_hash(self, rhs: "CsrMatrix", sort_output: bool = False, reference_order: bool = False) -> "CsrMatrix":
         """``mul_hash::<B1, B2>`` (spam_csr/src/mul_hash.rs:13-36); ``sort_output`` is B2.
+        ``reference_order`` (with B2 = false) asks for the reference's exact unsorted layout — linprobe slot
+        order — instead of this library's table order (rows of at most 4096 entries).
 
         Two phases exactly like the reference: symbolic gives nnz, the caller-side Vecs are allocated to
         that capacity (mul_hash.rs:119), numeric fills them."""
@@ -257,7 +260,8 @@ class CsrMatrix:
             indices = np.empty(nnz.value, dtype=np.uint64)
             vals = np.empty(nnz.value, dtype=self.vals.dtype)
             fn = L.spam_spgemm_numeric_f64 if self.vals.dtype == np.float64 else L.spam_spgemm_numeric_f32
-            check(fn(plan, int(bool(sort_output)), _vp(offsets), _vp(indices), _vp(vals)))
+            order = 1 if sort_output else (2 if reference_order else 0)
+            check(fn(plan, order, _vp(offsets), _vp(indices), _vp(vals)))
         finally:
             L.spam_spgemm_plan_free(plan)
         return CsrMatrix(self._rows, rhs._cols, vals, indices, offsets, is_sorted=sort_output)

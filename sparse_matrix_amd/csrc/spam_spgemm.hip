@@ -1088,6 +1088,122 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void sort_rows_kernel(const ui
   }
 }
 
+// ---- reference slot order (sort_rows = 2) --------------------------------------------------------------
+// The reference emits an unsorted row in linprobe SLOT order (map.rs:59-63), which depends on the order keys were
+// first inserted (A-row storage order x B-row storage order).  Sequential linear probing in insertion order gives
+// the same layout as the history-independent table in which an earlier key always takes precedence over a later one
+// (every slot between a key's home and its position holds an earlier key), and that table can be built in parallel:
+//   1. walk the row's product stream once more; a scratch table records, per distinct column, the smallest
+//      stream position it occurs at (LDS atomicMin);
+//   2. insert every column into the real table (capacity max(16, 2*next_pow2(nnz)), home (col*107) & mask) with a
+//      64-bit LDS atomicMax on (~position, col): a higher-priority arrival evicts the resident, which moves on;
+//   3. rank the occupied slots and rewrite the row of C (already computed, in any order) in that order.
+// One 1024-thread workgroup per row, rows of up to 4096 entries (table <= 8192 slots = 128 KB of LDS in all).
+template <class T>
+__global__ __launch_bounds__(1024) void ref_order_kernel(const uint64_t* __restrict__ a_rp,
+                                                        const uint32_t* __restrict__ a_col,
+                                                        const uint64_t* __restrict__ b_rp,
+                                                        const uint32_t* __restrict__ b_col,
+                                                        const uint32_t* __restrict__ rows_list, uint32_t nrows,
+                                                        const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ c_col,
+                                                        T* __restrict__ c_val) {
+  constexpr int TPB = 1024, SEG = 1024, CAP = 8192, MAXN = 4096;
+  __shared__ unsigned long long t2[CAP];                        // the reference-layout table: (~pos, col)
+  __shared__ __attribute__((aligned(16))) uint32_t t1[2 * CAP];  // scratch: keys | minpos, later rank | staging
+  __shared__ uint32_t seg_start[SEG + 1];
+  __shared__ uint32_t seg_lo[SEG];
+  __shared__ uint32_t wsum[TPB / 64 + 1];
+  uint32_t* k1 = t1;
+  uint32_t* mp = t1 + CAP;
+  for (uint32_t ri = blockIdx.x; ri < nrows; ri += gridDim.x) {
+    const uint32_t row = rows_list[ri];
+    const uint64_t out0 = c_rp[row];
+    const uint32_t n = (uint32_t)(c_rp[row + 1] - out0);
+    const uint32_t cap = table_size_for(n), mask = cap - 1;
+    for (uint32_t i = threadIdx.x; i < cap; i += TPB) {
+      k1[i] = EMPTY_KEY;
+      mp[i] = 0xFFFFFFFFu;
+      t2[i] = 0ull;
+    }
+    __syncthreads();
+    // 1. first-occurrence position of every distinct column
+    const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
+    uint32_t done = 0;  // products in earlier batches
+    for (uint64_t pb = ps; pb < pe; pb += SEG) {
+      const uint64_t p = pb + threadIdx.x;
+      uint32_t lo = 0, len = 0;
+      if (p < pe) {
+        const uint32_t k = a_col[p];
+        lo = (uint32_t)b_rp[k];
+        len = (uint32_t)b_rp[k + 1] - lo;
+      }
+      const uint32_t st = block_excl_scan<TPB>(len, wsum);
+      seg_start[threadIdx.x] = st;
+      seg_lo[threadIdx.x] = lo;
+      __syncthreads();
+      const uint32_t total = wsum[TPB / 64];
+      if (threadIdx.x == 0) seg_start[SEG] = total;
+      __syncthreads();
+      for (uint32_t idx = threadIdx.x; idx < total; idx += TPB) {
+        const uint32_t sg = seg_find(seg_start, SEG, idx);
+        const uint32_t key = b_col[seg_lo[sg] + (idx - seg_start[sg])];
+        uint32_t h = (key * HASH_SCAL) & mask;
+        for (;;) {
+          const uint32_t old = atomicCAS(&k1[h], EMPTY_KEY, key);
+          if (old == EMPTY_KEY || old == key) break;
+          h = (h + 1) & mask;
+        }
+        atomicMin(&mp[h], done + idx);
+      }
+      done += total;
+      __syncthreads();
+    }
+    // 2. priority insertion into the reference-layout table
+    for (uint32_t i = threadIdx.x; i < cap; i += TPB) {
+      const uint32_t key = k1[i];
+      if (key == EMPTY_KEY) continue;
+      unsigned long long v = ((unsigned long long)(~mp[i]) << 32) | key;
+      uint32_t h = (key * HASH_SCAL) & mask;
+      for (;;) {
+        const unsigned long long old = atomicMax(&t2[h], v);
+        if (old == 0ull) break;
+        if (old < v) v = old;  // we evicted a later key: it carries on from the next slot
+        h = (h + 1) & mask;
+      }
+    }
+    __syncthreads();
+    // 3. rank of every occupied slot = position in the drained row; t1 is free again
+    uint16_t* rank = (uint16_t*)t1;               // [CAP]
+    uint32_t* scol = t1 + CAP / 2;                // [MAXN]
+    T* sval = (T*)(t1 + CAP / 2 + MAXN);          // [MAXN]
+    const uint32_t spt = cap >= TPB ? cap / TPB : 1;
+    uint32_t cnt = 0;
+    if (threadIdx.x * spt < cap)
+      for (uint32_t j = 0; j < spt; ++j) cnt += t2[threadIdx.x * spt + j] != 0ull;
+    uint32_t r = block_excl_scan<TPB>(cnt, wsum);
+    if (threadIdx.x * spt < cap)
+      for (uint32_t j = 0; j < spt; ++j) {
+        const uint32_t sl = threadIdx.x * spt + j;
+        if (t2[sl] != 0ull) rank[sl] = (uint16_t)r++;
+      }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      const uint32_t key = c_col[out0 + i];
+      uint32_t h = (key * HASH_SCAL) & mask;
+      while ((uint32_t)t2[h] != key || t2[h] == 0ull) h = (h + 1) & mask;
+      const uint32_t rr = rank[h];
+      scol[rr] = key;
+      sval[rr] = c_val[out0 + i];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      c_col[out0 + i] = scol[i];
+      c_val[out0 + i] = sval[i];
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace spam
 
 // ---- plan ---------------------------------------------------------------------------------------------
@@ -1336,6 +1452,10 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
   SPAM_TRY((launch_num_row<T, 1024, 8192>(a, b, L + 3ull * rows, hc[3], rn, crp, cc, cv, s)));
 
   const uint32_t n_hnum = hc[NNUM - 1];
+  if (sort_rows == 2 && n_hnum)
+    return set_error(SPAM_E_UNSUPPORTED,
+                     "reference slot order (sort_rows = 2) is built in LDS and serves rows of at most 4096 entries; "
+                     "%u rows of this product are longer", n_hnum);
   if (n_hnum) {
     const char* dbg_env = getenv("SPAM_DBG_HEAVY");  // timing ablations only (results are wrong when set)
     const int dbg_heavy = dbg_env ? atoi(dbg_env) : 0;
@@ -1364,9 +1484,9 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     if (hsplit[0]) SPAM_NUM_HEAVY(BPOS_, SORT_, l_normal, hsplit[0], 1u, qcnt + 3);                     \
   } while (0)
     if (p->use_bpos) {
-      if (sort_rows) SPAM_NUM_HEAVY_BOTH(true, true); else SPAM_NUM_HEAVY_BOTH(true, false);
+      if (sort_rows == 1) SPAM_NUM_HEAVY_BOTH(true, true); else SPAM_NUM_HEAVY_BOTH(true, false);
     } else {
-      if (sort_rows) SPAM_NUM_HEAVY_BOTH(false, true); else SPAM_NUM_HEAVY_BOTH(false, false);
+      if (sort_rows == 1) SPAM_NUM_HEAVY_BOTH(false, true); else SPAM_NUM_HEAVY_BOTH(false, false);
     }
 #undef SPAM_NUM_HEAVY_BOTH
 #undef SPAM_NUM_HEAVY
@@ -1380,7 +1500,15 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
               hg[4], hg[5], hg[6], hg[7], hg[8], hg[9], hg[10]);
     st.heavy_dense_groups = hg[0], st.heavy_hash_groups = hg[1], st.heavy_dense_nnz = hg[2], st.heavy_hash_nnz = hg[3];
   }
-  if (sort_rows) {
+  if (sort_rows == 2) {
+    // reference slot order: every non-empty row has at most 4096 entries here (checked above)
+    for (int bin = 0; bin < NNUM - 1; ++bin) {
+      if (!hc[bin]) continue;
+      ref_order_kernel<T><<<std::min<uint32_t>(hc[bin], 8192), 1024, 0, s>>>(
+          a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, L + (uint64_t)bin * rows, hc[bin], crp, cc, cv);
+      SPAM_CHECK_LAUNCH();
+    }
+  } else if (sort_rows) {
     SPAM_TRY((launch_sort<T, 16, 64>(L + 0ull * rows, hc[0], crp, cc, cv, s)));
     SPAM_TRY((launch_sort<T, 64, 512>(L + 1ull * rows, hc[1], crp, cc, cv, s)));
     SPAM_TRY((launch_sort<T, 256, 2048>(L + 2ull * rows, hc[2], crp, cc, cv, s)));
@@ -1396,7 +1524,7 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
   if (!c) return set_error(SPAM_E_OOM, "host allocation failed");
   c->rows = a->rows, c->cols = b->cols, c->nnz = st.nnz_c, c->dtype = a->dtype;
   // heavy rows are always sorted; hash rows only when asked (the const generic B2)
-  c->is_sorted = sort_rows ? 1 : 0;
+  c->is_sorted = sort_rows == 1 ? 1 : 0;
   c->row_ptr = (uint64_t*)p->c_row_ptr.release();
   c->col_idx = (uint32_t*)ccol.release();
   c->vals = cval.release();

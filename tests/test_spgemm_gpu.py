@@ -205,7 +205,7 @@ def test_matrix_market_bench_shape(spam, oracle, tmp_path):
     CsrMatrix::from (sorted) -> m.mul_hash(&m) unsorted, against the oracle on the same parsed matrix."""
     from sparse_matrix_amd.mmio import into_float_matrix_market, parse_matrix_market
 
-    m = synth.rmat(8, signed=True)
+    m = synth.rmat(8)
     off, idx, val = csr_np(m)
     ents = {(r, int(idx[p])): float(val[p]) for r in range(m.rows) for p in range(int(off[r]), int(off[r + 1]))}
     f = tmp_path / "rmat8.mtx"
@@ -216,4 +216,73 @@ def test_matrix_market_bench_shape(spam, oracle, tmp_path):
     assert np.array_equal(A.offsets, off) and np.array_equal(A.indices, idx) and np.array_equal(A.vals, val)
     C = A * A  # impl Mul -> CsrMatrix<T, false>
     want = oracle.mul_hash((off, idx, val), (off, idx, val), sort_rows=False)
-    assert_csr_parity((C.offsets, C.indices, C.vals), want, False, 1e-9)  # signed data: looser relative bar
+    assert_csr_parity((C.offsets, C.indices, C.vals), want, False, F64_RTOL)
+
+
+def _exact_unsorted(spam, oracle, ma, mb, a_sorted=True, b_sorted=True, rtol=F64_RTOL):
+    A, a = _mk(spam, ma, a_sorted)
+    B, b = _mk(spam, mb, b_sorted)
+    C = A.mul_hash(B, sort_output=False, reference_order=True)
+    wo, wi, wv = oracle.mul_hash(a, b, sort_rows=False)
+    assert np.array_equal(C.offsets, wo), "row_ptr"
+    assert np.array_equal(C.indices, wi), "col_idx must equal the reference's linprobe slot order"
+    if len(wv):
+        assert np.max(np.abs(C.vals - wv) / np.abs(wv)) <= rtol
+    return C
+
+
+def test_reference_slot_order_small_kats(spam):
+    """The hand-derived slot orders of tests/golden/linprobe_kat.json through the GPU: a 1 x n row times the
+    identity inserts the columns in the given order."""
+    import json, os
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "linprobe_kat.json")))
+    for case in gold["map_drain_order"]:
+        keys = case["insert"]
+        uniq = list(dict.fromkeys(keys))
+        if len(uniq) != len(keys):
+            continue  # a CSR row holds distinct columns; repeated keys are covered by the products below
+        n = max(keys) + 1
+        A = spam.CsrMatrix(1, n, np.ones(len(keys)), np.array(keys, dtype=np.uint64), np.array([0, len(keys)], dtype=np.uint64), False)
+        C = A.mul_hash(spam.CsrMatrix.identity(n), reference_order=True)
+        assert C.indices.tolist() == case["drain"], (keys, C.indices.tolist())
+
+
+def test_reference_slot_order_products(spam, oracle):
+    """Bit-exact unsorted col_idx against the oracle (the reference's sequential linprobe order): banded cfg1,
+    R-MAT with collision runs and repeated keys, unsorted inputs, rectangular shapes, f32."""
+    m = synth.banded(10000, 5)
+    _exact_unsorted(spam, oracle, m, m)
+    for scale in (6, 9, 10):
+        m = synth.rmat(scale)
+        _exact_unsorted(spam, oracle, m, m)
+    _exact_unsorted(spam, oracle, synth.random_csr(200, 300, 0.05, seed=31, signed=False, sort_rows=False),
+                    synth.random_csr(300, 500, 0.04, seed=32, signed=False, sort_rows=False), a_sorted=False, b_sorted=False)
+    _exact_unsorted(spam, oracle, synth.random_csr(3, 2000, 0.9, seed=33, signed=False),
+                    synth.random_csr(2000, 4000, 0.01, seed=34, signed=False))       # rows of ~4000 entries: 8192-slot table
+    m = synth.rmat(9, dtype=torch.float32)
+    _exact_unsorted(spam, oracle, m, m, rtol=F32_RTOL)
+
+
+def test_reference_slot_order_property_small_random(spam, oracle):
+    """The reference's own test shape (dims 1..4 and up to 40, unsorted CSR from DOK, tests.rs:356-371): col_idx
+    bit-exact for every case."""
+    rng = np.random.default_rng(99)
+    for case in range(80):
+        l, m, n = rng.integers(1, 41, 3) if case % 2 else rng.integers(1, 5, 3)
+        da = {(int(rng.integers(l)), int(rng.integers(m))): float(rng.uniform(0.5, 1.5)) for _ in range(int(rng.integers(0, 2 * l * m + 1)))}
+        db = {(int(rng.integers(m)), int(rng.integers(n))): float(rng.uniform(0.5, 1.5)) for _ in range(int(rng.integers(0, 2 * m * n + 1)))}
+        A = spam.CsrMatrix.from_dok((l, m), da, rng=rng)
+        B = spam.CsrMatrix.from_dok((m, n), db, rng=rng)
+        C = A.mul_hash(B, reference_order=True)
+        wo, wi, wv = oracle.mul_hash((A.offsets, A.indices, A.vals), (B.offsets, B.indices, B.vals), sort_rows=False)
+        assert np.array_equal(C.offsets, wo) and np.array_equal(C.indices, wi)
+        assert C.invariants()
+
+
+def test_reference_slot_order_refuses_long_rows(spam):
+    m = synth.rmat(13)
+    A, _ = _mk(spam, m)
+    with pytest.raises(spam.SpamError) as e:
+        A.mul_hash(A, reference_order=True)
+    assert e.value.code == 6
