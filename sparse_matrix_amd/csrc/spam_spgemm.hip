@@ -31,8 +31,10 @@
 namespace spam {
 
 // ---- geometry -------------------------------------------------------------------------------------
-constexpr int CW_SHIFT = 14;
-constexpr uint32_t CW = 1u << CW_SHIFT;         // numeric chunk: 16384 columns (128 KB of f64 + 16 KB flags)
+// numeric chunk width of the heavy path, chosen per product: 2^13 columns with 512-thread workgroups (80 KB of LDS,
+// two workgroups per CU overlap each other's latencies) when B has at most 4 M columns, else 2^14 with 1024 threads.
+constexpr int CW_SHIFT_SMALL = 13, CW_SHIFT_LARGE = 14;
+constexpr uint32_t MAXCH_SMALL = 512, MAXCH_LARGE = 1024;  // chunks per row the LDS group list can hold
 
 constexpr uint32_t HEAVY_GRID = 8192;           // persistent workgroups of the heavy kernels (1 fits per CU)
 
@@ -494,7 +496,8 @@ __global__ __launch_bounds__(TPB) void num_row_kernel(
 // ---- heavy rows: B rows pre-split at numeric-chunk boundaries ---------------------------------------
 // bpos[j * rows_b + k] = first position q in B's row k with col[q] >= j * CW, j = 0..nchunks (absolute, u32).
 __global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
-                                                  uint32_t rows_b, uint32_t nchunks, uint32_t* __restrict__ bpos) {
+                                                  uint32_t rows_b, uint32_t nchunks, int CW_SHIFT,
+                                                  uint32_t* __restrict__ bpos) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ 
 // Symbolic pass for heavy rows: one workgroup per row, a 2^20-column bitmap window in LDS (LDS atomic OR),
 // then a popcount per numeric chunk.  The row's k list stays in LDS across windows when it fits.
 constexpr int BM_WORDS = 32768;                  // 128 KB bitmap = 2^20 columns = 64 numeric chunks per window
-constexpr int BM_CHUNKS = (BM_WORDS * 32) / CW;  // 64
+constexpr int BM_CHUNKS_MAX = (BM_WORDS * 32) >> CW_SHIFT_SMALL;  // 128 chunks per window at most
 constexpr int BM_SHIFT = 20;
 
 template <bool USE_BPOS>
@@ -526,16 +529,17 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
                                                         const uint32_t* __restrict__ b_col,
                                                         const uint32_t* __restrict__ bpos, uint32_t rows_b,
                                                         const uint32_t* __restrict__ heavy_rows, uint32_t n_heavy,
-                                                        uint32_t nchunks, uint32_t* __restrict__ hcnt,
+                                                        uint32_t nchunks, int cw_shift, uint32_t* __restrict__ hcnt,
                                                         uint32_t* __restrict__ queue) {
   constexpr int SEG = 1024;
+  const uint32_t BM_CHUNKS = (BM_WORDS * 32u) >> cw_shift;  // numeric chunks per bitmap window
   __shared__ uint32_t item_s;
   __shared__ uint32_t bm[BM_WORDS];
   __shared__ uint32_t seg_start[SEG + 1];
   __shared__ uint32_t seg_lo[SEG];
   __shared__ uint32_t klist[SEG];
   __shared__ uint32_t wsum[17];
-  __shared__ uint32_t ccnt[BM_CHUNKS];
+  __shared__ uint32_t ccnt[BM_CHUNKS_MAX];
   for (int i = threadIdx.x; i < BM_WORDS; i += 1024) bm[i] = 0;
   if (threadIdx.x < BM_CHUNKS) ccnt[threadIdx.x] = 0;
   __syncthreads();
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
         const uint32_t v = bm[i * 1024 + threadIdx.x];
         if (v) bm[i * 1024 + threadIdx.x] = 0;
         const uint32_t n = wave_sum_u32(__popc(v));
-        if ((threadIdx.x & 63) == 0 && n) atomicAdd(&ccnt[2 * i + (threadIdx.x >> 9)], n);
+        if ((threadIdx.x & 63) == 0 && n) atomicAdd(&ccnt[(i * 1024 + threadIdx.x) >> (cw_shift - 5)], n);
       }
       __syncthreads();
       if (threadIdx.x < BM_CHUNKS) {
@@ -679,7 +683,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void num_hash_kernel(
     if (valid) {
       const int lane = threadIdx.x & 63;
       const int gshift = lane & ~(G - 1);
-      const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+      const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1);
       uint32_t run = 0;
       for (uint32_t base = 0; base < tsize; base += G) {
         const uint32_t slot = base + gl;
@@ -742,15 +746,14 @@ __global__ __launch_bounds__(256) void split_giant_kernel(const uint32_t* __rest
 //     of HTSIZE slots laid over the same LDS (keys u32 + values T), compaction in slot order.
 // Either way a group writes a contiguous, precomputed piece of C's row (hoff), groups are in increasing
 // column order, and every touched LDS slot is reset while it is read out.
-constexpr uint32_t HWIN = 2048;    // grouping window / dense threshold (entries)
-constexpr uint32_t HCAP = 4096;    // a hash group holds fewer than HCAP entries (load < 0.5)
-constexpr uint32_t HTSIZE = 8192;  // slots
-constexpr uint32_t MAX_HEAVY_CHUNKS = 1024;
+//   HTSIZE = CW/2 slots;  HCAP = load * HTSIZE: a hash group holds fewer entries;  HWIN = HCAP/2: grouping
+//   window / dense threshold.
+constexpr uint32_t HEAVY_LOAD_16THS = 12;  // max load factor of a heavy hash group in sixteenths (12 = 0.75)
 constexpr uint32_t GIANT_NNZ_A = 1024;  // A rows longer than this are cut into GIANT_PARTS work items
 constexpr uint32_t GIANT_PARTS = 16;
 
-template <class T, bool USE_BPOS, bool SORT>
-__global__ __launch_bounds__(1024) void num_heavy_kernel(
+template <class T, bool USE_BPOS, bool SORT, int TPB, int CWS>
+__global__ __launch_bounds__(TPB) void num_heavy_kernel(
     const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
     const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col, const T* __restrict__ b_val,
     const uint32_t* __restrict__ bpos, uint32_t rows_b, const uint32_t* __restrict__ rows_list, uint32_t n_rows,
@@ -758,7 +761,11 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
     const uint32_t* __restrict__ hcnt, const uint32_t* __restrict__ hoff, const uint32_t* __restrict__ row_nnz,
     const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ c_col, T* __restrict__ c_val,
     unsigned long long* __restrict__ gstats, int dbg) {
-  constexpr int SEG = 256;
+  constexpr int SEG = TPB / 4;
+  constexpr int CW_SHIFT = CWS;
+  constexpr uint32_t CW = 1u << CWS, HTSIZE = CW / 2, HWIN = HEAVY_LOAD_16THS * HTSIZE / 32, HCAP = 2 * HWIN;
+  constexpr uint32_t MAX_HEAVY_CHUNKS = TPB > 512 ? MAXCH_LARGE : MAXCH_SMALL;
+  static_assert(CW == 16 * TPB, "one thread drains 16 consecutive columns");
   __shared__ __attribute__((aligned(16))) T acc[CW];
   __shared__ __attribute__((aligned(16))) uint8_t flags[CW];
   __shared__ uint32_t seg_start[SEG + 1];
@@ -766,19 +773,19 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
   __shared__ T seg_av[SEG];
   __shared__ uint32_t klist[SEG];
   __shared__ T kval[SEG];
-  __shared__ uint32_t wsum[17];
+  __shared__ uint32_t wsum[TPB / 64 + 1];
   __shared__ uint16_t gbeg[MAX_HEAVY_CHUNKS + 1];
   __shared__ uint32_t goff[MAX_HEAVY_CHUNKS + 1];
   __shared__ uint32_t ng_s, item_s;
   static_assert(sizeof(T) * CW >= HTSIZE * (4 + sizeof(T)), "hash table must fit the dense accumulator's LDS");
-  static_assert(HCAP == 2 * HWIN && HTSIZE >= 2 * HCAP, "a group of non-dense chunks sharing a window holds < HCAP entries");
+  static_assert(HCAP <= HTSIZE * 13 / 16, "a group of non-dense chunks sharing a window holds < HCAP entries");
   uint32_t* hkeys = (uint32_t*)acc;
   T* hvals = (T*)((char*)acc + HTSIZE * 4);
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4* f4 = (u32x4*)flags;
   u32x4* a4 = (u32x4*)acc;
-  f4[threadIdx.x] = (u32x4)(0u);  // 1024 x 16 = CW flags
-  for (int i = threadIdx.x; i < (int)(sizeof(T) * CW / 16); i += 1024) a4[i] = (u32x4)(0u);
+  f4[threadIdx.x] = (u32x4)(0u);  // TPB x 16 = CW flags
+  for (int i = threadIdx.x; i < (int)(sizeof(T) * CW / 16); i += TPB) a4[i] = (u32x4)(0u);
   int mode = 0;  // 0: acc region all zero (dense-clean); 1: hkeys all EMPTY, hvals zero (hash-clean)
   __syncthreads();
   unsigned long long t_row = 0, t_a = 0, t_p = 0, t_c = 0, t_da = 0, t_dp = 0, t_dc = 0, t0 = 0, t1 = 0;
@@ -818,14 +825,14 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
         else
           startflag = dj || (hc[j - 1] > HWIN) || (myoff / HWIN != ho[j - 1] / HWIN);
       }
-      const uint32_t pos = block_excl_scan_1024(startflag, wsum);
+      const uint32_t pos = block_excl_scan<TPB>(startflag, wsum);
       if (startflag) {
         gbeg[pos] = (uint16_t)j;
         goff[pos] = myoff;
       }
       __syncthreads();
       if (threadIdx.x == 0) {
-        const uint32_t ng = wsum[16];
+        const uint32_t ng = wsum[TPB / 64];
         ng_s = ng;
         gbeg[ng] = (uint16_t)nchunks;
         goff[ng] = row_nnz[row];
@@ -850,11 +857,11 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
       }
       // make the LDS region clean for this group's mode
       if (dense && mode == 1) {
-        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += 1024) a4[i] = (u32x4)(0u);
+        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += TPB) a4[i] = (u32x4)(0u);
         mode = 0;
         __syncthreads();
       } else if (!dense && mode == 0) {
-        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += 1024) a4[i] = (u32x4)(EMPTY_KEY);
+        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += TPB) a4[i] = (u32x4)(EMPTY_KEY);
         mode = 1;
         __syncthreads();
       }
@@ -881,13 +888,13 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
           }
           if (dbg & 1) len = 0;
         }
-        const uint32_t st = block_excl_scan_1024(len, wsum);
+        const uint32_t st = block_excl_scan<TPB>(len, wsum);
         if (threadIdx.x < SEG) {
           seg_start[threadIdx.x] = st;
           seg_lo[threadIdx.x] = lo;
         }
         __syncthreads();
-        const uint32_t total = wsum[16];
+        const uint32_t total = wsum[TPB / 64];
         if (threadIdx.x == 0) seg_start[SEG] = total;
         __syncthreads();
         if (timing) {
@@ -896,9 +903,9 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
           t0 = t1;
         }
         // products per lane and round: HEAVY_U when there is enough work, fewer when the group is small so that
-        // all 16 wavefronts share it (the chain of LDS round trips per lane is what a small group waits for)
-        const uint32_t upl = total >= 1024 * HEAVY_U ? HEAVY_U : (total + 1023) / 1024;
-        for (uint32_t wb = (threadIdx.x >> 6) * (64 * upl); wb < total; wb += 1024 * upl) {
+        // all wavefronts share it (the chain of LDS round trips per lane is what a small group waits for)
+        const uint32_t upl = total >= TPB * HEAVY_U ? HEAVY_U : (total + TPB - 1) / TPB;
+        for (uint32_t wb = (threadIdx.x >> 6) * (64 * upl); wb < total; wb += TPB * upl) {
           const uint32_t idx0 = wb + (threadIdx.x & 63);
           uint32_t sg = seg_find(seg_start, SEG, idx0 < total ? idx0 : total - 1);
           uint32_t cols[HEAVY_U];
@@ -953,7 +960,7 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
         // column order: thread t owns columns [16 t, 16 t + 16)
         const u32x4 w = f4[threadIdx.x];
         const uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
-        const uint32_t ex = block_excl_scan_1024(n, wsum);
+        const uint32_t ex = block_excl_scan<TPB>(n, wsum);
         if (n) {
           out += ex;
           f4[threadIdx.x] = (u32x4)(0u);
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
         // last), after which the group's entries are slots [0, cnt)
         for (uint32_t k = 2; k <= HTSIZE; k <<= 1) {
           for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < HTSIZE; i += 1024) {
+            for (uint32_t i = threadIdx.x; i < HTSIZE; i += TPB) {
               const uint32_t l = i ^ j;
               if (l > i) {
                 const uint32_t ki = hkeys[i], kl = hkeys[l];
@@ -990,7 +997,7 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
             __syncthreads();
           }
         }
-        for (uint32_t i = threadIdx.x; i < cnt; i += 1024) {
+        for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
           c_col[out + i] = hkeys[i];
           c_val[out + i] = hvals[i];
           hkeys[i] = EMPTY_KEY;
@@ -998,7 +1005,7 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
         }
       } else {
         // slot order (map.rs:59-63): thread t owns slots [8 t, 8 t + 8)
-        constexpr int SPT = HTSIZE / 1024;
+        constexpr int SPT = HTSIZE / TPB;
         uint32_t kk[SPT];
         uint32_t n = 0;
 #pragma unroll
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(1024) void num_heavy_kernel(
           kk[j] = hkeys[threadIdx.x * SPT + j];
           n += kk[j] != EMPTY_KEY;
         }
-        const uint32_t ex = block_excl_scan_1024(n, wsum);
+        const uint32_t ex = block_excl_scan<TPB>(n, wsum);
         if (n) {
           out += ex;
 #pragma unroll
@@ -1216,6 +1223,7 @@ struct spam_spgemm_plan {
   spam::DevBuf hcnt, hoff;   // u32[n_heavy * nchunks]
   spam::DevBuf bpos;         // u32[(nchunks + 1) * rows_b]
   uint32_t n_heavy = 0, nchunks = 0;
+  int cw_shift = spam::CW_SHIFT_LARGE;
   bool use_bpos = false;
   spam_spgemm_stats st{};
   hipEvent_t ev[6] = {};
@@ -1365,11 +1373,17 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
 
   // heavy rows: dense flags per symbolic chunk
   p->n_heavy = hc[NSYM - 1];
-  p->nchunks = (uint32_t)((b->cols + CW - 1) >> CW_SHIFT);
+  {
+    const char* cfg = getenv("SPAM_HEAVY_TPB");  // 512 / 1024: force a heavy-path geometry (A/B runs)
+    const uint64_t nch_small = (b->cols + (1u << CW_SHIFT_SMALL) - 1) >> CW_SHIFT_SMALL;
+    const bool small_ok = nch_small <= MAXCH_SMALL;
+    p->cw_shift = (small_ok && cfg && atoi(cfg) == 512) ? CW_SHIFT_SMALL : CW_SHIFT_LARGE;  // 512 measured slower (more, smaller groups)
+    p->nchunks = (uint32_t)((b->cols + (1ull << p->cw_shift) - 1) >> p->cw_shift);
+  }
   if (p->n_heavy) {
-    if (p->nchunks > MAX_HEAVY_CHUNKS)
+    if (p->nchunks > MAXCH_LARGE)
       return set_error(SPAM_E_UNSUPPORTED, "rows with more than 4096 intermediate products need cols(B) <= %u",
-                       MAX_HEAVY_CHUNKS * CW);
+                       MAXCH_LARGE << CW_SHIFT_LARGE);
     SPAM_TRY(p->heavy_rows.alloc((uint64_t)p->n_heavy * 4));
     SPAM_HIP_TRY(hipMemcpyAsync(p->heavy_rows.p, L + (uint64_t)(NSYM - 1) * rows, (uint64_t)p->n_heavy * 4,
                                 hipMemcpyDeviceToDevice, s));
@@ -1377,7 +1391,7 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     if (p->use_bpos) {
       SPAM_TRY(p->bpos.alloc((uint64_t)(p->nchunks + 1) * b->rows * 4));
       unsigned grid = (unsigned)std::min<uint64_t>((b->rows + 3) / 4, 16384);
-      bpos_kernel<<<grid, 256, 0, s>>>(b->row_ptr, b->col_idx, (uint32_t)b->rows, p->nchunks, p->bpos.as<uint32_t>());
+      bpos_kernel<<<grid, 256, 0, s>>>(b->row_ptr, b->col_idx, (uint32_t)b->rows, p->nchunks, p->cw_shift, p->bpos.as<uint32_t>());
       SPAM_CHECK_LAUNCH();
     }
     SPAM_TRY(p->hcnt.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
@@ -1386,11 +1400,11 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     if (p->use_bpos)
       sym_heavy_kernel<true><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, p->bpos.as<uint32_t>(),
                                                    (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
-                                                   p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
+                                                   p->cw_shift, p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
     else
       sym_heavy_kernel<false><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, nullptr,
                                                     (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
-                                                    p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
+                                                    p->cw_shift, p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
     SPAM_CHECK_LAUNCH();
     heavy_finalize_kernel<<<(p->n_heavy + 3) / 4, 256, 0, s>>>(p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
                                                               p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn);
@@ -1472,12 +1486,19 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     uint32_t hsplit[2];
     SPAM_HIP_TRY(hipMemcpyAsync(hsplit, qcnt, 8, hipMemcpyDeviceToHost, s));
     SPAM_HIP_TRY(hipStreamSynchronize(s));
-#define SPAM_NUM_HEAVY(BPOS_, SORT_, LIST_, N_, PARTS_, Q_)                                                       \
-  num_heavy_kernel<T, BPOS_, SORT_><<<std::min<uint32_t>((N_) * (PARTS_), HEAVY_GRID), 1024, 0, s>>>(              \
+#define SPAM_NUM_HEAVY_G(BPOS_, SORT_, TPB_, CWS_, LIST_, N_, PARTS_, Q_)                                          \
+  num_heavy_kernel<T, BPOS_, SORT_, TPB_, CWS_><<<std::min<uint32_t>((N_) * (PARTS_), HEAVY_GRID), TPB_, 0, s>>>( \
       a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals,                      \
       BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, LIST_, N_, PARTS_, Q_,                         \
       p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn, crp, cc, cv, \
       gst.as<unsigned long long>(), dbg_heavy)
+#define SPAM_NUM_HEAVY(BPOS_, SORT_, LIST_, N_, PARTS_, Q_)                                       \
+  do {                                                                                            \
+    if (p->cw_shift == CW_SHIFT_SMALL)                                                            \
+      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 512, CW_SHIFT_SMALL, LIST_, N_, PARTS_, Q_);                 \
+    else                                                                                          \
+      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 1024, CW_SHIFT_LARGE, LIST_, N_, PARTS_, Q_);                \
+  } while (0)
 #define SPAM_NUM_HEAVY_BOTH(BPOS_, SORT_)                                                              \
   do {                                                                                                 \
     if (hsplit[1]) SPAM_NUM_HEAVY(BPOS_, SORT_, l_giant, hsplit[1], GIANT_PARTS, qcnt + 2); /* first */ \
@@ -1490,6 +1511,7 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     }
 #undef SPAM_NUM_HEAVY_BOTH
 #undef SPAM_NUM_HEAVY
+#undef SPAM_NUM_HEAVY_G
     SPAM_CHECK_LAUNCH();
     st.heavy_items = n_hnum;
     unsigned long long hg[16];
