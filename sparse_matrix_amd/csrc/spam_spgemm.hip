@@ -844,6 +844,7 @@ __global__ __launch_bounds__(TPB) void num_heavy_kernel(
       t1 = clock64();
       t_row += t1 - t0;
     }
+    uint32_t pf_lo = 0, pf_len = 0, pf_g = 0xFFFFFFFFu;
     for (uint32_t g = part; g < ng; g += parts) {
       if (timing) t0 = clock64();
       const uint32_t j0 = gbeg[g], j1 = gbeg[g + 1];
@@ -877,17 +878,25 @@ __global__ __launch_bounds__(TPB) void num_heavy_kernel(
             k = a_col[p];
             seg_av[threadIdx.x] = a_val[p];
           }
-          if (dbg & 4) {
-            lo = k, len = 0;
-          } else if (USE_BPOS) {
-            lo = bpos[(uint64_t)j0 * rows_b + k];
-            len = bpos[(uint64_t)j1 * rows_b + k] - lo;
+          if (USE_BPOS) {
+            if (cached && pf_g == g) {  // fetched while the previous group was being accumulated
+              lo = pf_lo;
+              len = pf_len;
+            } else {
+              lo = bpos[(uint64_t)j0 * rows_b + k];
+              len = bpos[(uint64_t)j1 * rows_b + k] - lo;
+            }
+            const uint32_t gn = g + parts;
+            if (cached && gn < ng) {  // this lane's B-split lookups of the next group fly during this one
+              pf_lo = bpos[(uint64_t)gbeg[gn] * rows_b + k];
+              pf_len = bpos[(uint64_t)gbeg[gn + 1] * rows_b + k] - pf_lo;
+            }
           } else {
             lo = (uint32_t)b_rp[k];
             len = (uint32_t)b_rp[k + 1] - lo;
           }
-          if (dbg & 1) len = 0;
         }
+        pf_g = g + parts;
         const uint32_t st = block_excl_scan<TPB>(len, wsum);
         if (threadIdx.x < SEG) {
           seg_start[threadIdx.x] = st;
@@ -918,19 +927,9 @@ __global__ __launch_bounds__(TPB) void num_heavy_kernel(
             if (j < upl && idx < total) {
               sg = seg_advance(seg_start, SEG, sg, idx);
               const uint32_t q = seg_lo[sg] + (idx - seg_start[sg]);
-              if (dbg & 16) {  // timing ablation: no product loads
-                cols[j] = c0 + (idx % (cnt < cspan ? cnt : cspan));
-                prods[j] = seg_av[sg];
-              } else {
-                cols[j] = b_col[q];
-                prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
-              }
+              cols[j] = b_col[q];
+              prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
             }
-          }
-          if (dbg & 8) {  // timing ablation: loads only
-#pragma unroll
-            for (int j = 0; j < HEAVY_U; ++j) asm volatile("" ::"v"(cols[j]), "v"(prods[j]));
-            continue;
           }
           bool okv[HEAVY_U];
 #pragma unroll
@@ -1471,7 +1470,7 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
                      "reference slot order (sort_rows = 2) is built in LDS and serves rows of at most 4096 entries; "
                      "%u rows of this product are longer", n_hnum);
   if (n_hnum) {
-    const char* dbg_env = getenv("SPAM_DBG_HEAVY");  // timing ablations only (results are wrong when set)
+    const char* dbg_env = getenv("SPAM_DBG_HEAVY");  // 32: print in-kernel phase timers (results unaffected)
     const int dbg_heavy = dbg_env ? atoi(dbg_env) : 0;
     const uint32_t* hl = L + (uint64_t)(NNUM - 1) * rows;
     DevBuf gst, split;
