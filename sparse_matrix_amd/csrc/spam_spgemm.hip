@@ -732,11 +732,29 @@ __global__ __launch_bounds__(256) void split_giant_kernel(const uint32_t* __rest
                                                          uint32_t* __restrict__ normal, uint32_t* __restrict__ giant,
                                                          uint32_t* __restrict__ counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t r = list[i];
-  const bool g = a_rp[r + 1] - a_rp[r] > thr;
-  const uint32_t pos = atomicAdd(&counts[g ? 1 : 0], 1u);
-  (g ? giant : normal)[pos] = r;
+  const int lane = threadIdx.x & 63;
+  uint32_t r = 0;
+  bool valid = i < n, g = false;
+  if (valid) {
+    r = list[i];
+    g = a_rp[r + 1] - a_rp[r] > thr;
+  }
+  // one atomic per wavefront and class, lanes ranked by ballot
+  const uint64_t mg = __ballot(valid && g), mn = __ballot(valid && !g);
+  uint32_t bg = 0, bn = 0;
+  if (lane == 0) {
+    if (mg) bg = atomicAdd(&counts[1], (uint32_t)__popcll(mg));
+    if (mn) bn = atomicAdd(&counts[0], (uint32_t)__popcll(mn));
+  }
+  bg = __shfl(bg, 0, 64);
+  bn = __shfl(bn, 0, 64);
+  if (valid) {
+    const uint64_t below = (1ull << lane) - 1;
+    if (g)
+      giant[bg + __popcll(mg & below)] = r;
+    else
+      normal[bn + __popcll(mn & below)] = r;
+  }
 }
 
 // Numeric pass for heavy rows: one workgroup per row.  The row's numeric chunks are grouped on the fly:
