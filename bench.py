@@ -163,7 +163,7 @@ def main():
             cores = oracle.hardware_threads()
             ts = []
             ref = None
-            for _ in range(4):
+            for _ in range(11):
                 t1 = time.perf_counter()
                 ref = oracle.spmv(a_host, xh, nthreads=cores)
                 ts.append(time.perf_counter() - t1)
@@ -251,10 +251,10 @@ def main():
 
             a_host = blk.cpu_numpy()
             flops_row, _ = oracle.rows_to_threads(a_host[0], a_host[1], a_host[0], 1)
-            # contiguous row sample holding ~2e8 intermediate products, taken from the middle of the matrix
+            # contiguous row sample holding ~2e9 intermediate products, taken from the middle of the matrix
             ps = np.concatenate([[0], np.cumsum(flops_row.astype(np.float64))])
             mid = n // 2
-            target = min(2e8, ps[-1] - ps[mid])
+            target = min(2e9, ps[-1] - ps[mid])
             r1 = int(np.searchsorted(ps, ps[mid] + target))
             r1 = max(mid + 1, min(r1, n))
             off = a_host[0][mid:r1 + 1] - a_host[0][mid]

@@ -120,8 +120,8 @@ int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y); /* device-resi
  *                         library's own table order: the same SET of (col, value) per row as the
  *                         reference, not its linprobe slot order.  sort_rows = 2 (SPAM_ORDER_REFERENCE)
  *                         reproduces the reference's unsorted output exactly — linprobe slot order,
- *                         map.rs:59-63 — for products whose rows hold at most 4096 entries, and fails with
- *                         SPAM_E_UNSUPPORTED otherwise.  Explicit zeros are kept (structure = symbolic
+ *                         map.rs:59-63 (rows above 4096 entries build their table in HBM: a verification
+ *                         path, several times slower).  Explicit zeros are kept (structure = symbolic
  *                         pattern), as in the reference. */
 #define SPAM_ORDER_TABLE 0
 #define SPAM_ORDER_SORTED 1

@@ -1228,6 +1228,195 @@ __global__ __launch_bounds__(1024) void ref_order_kernel(const uint64_t* __restr
   }
 }
 
+// ---- reference slot order for rows longer than 4096 entries (tables in HBM) ---------------------------
+// Same three steps as ref_order_kernel, but a 485 k-entry row needs the reference's 2^20-slot table, so:
+//   1. minpos_heavy_kernel: first stream position of every distinct column, chunk by chunk through a dense
+//      u32 array in LDS (2 numeric chunks = 32768 columns per pass, LDS atomicMin), written as (col, pos)
+//      pairs in column order into scratch arrays laid out like C;
+//   2. ref_order_long_kernel: one workgroup per row builds the priority table in its own HBM slab with 64-bit
+//      global atomicMax, ranks the occupied slots and rewrites the row of C in that order.
+// A verification path: global atomics and L1-bypassing loads throughout, not tuned.
+constexpr uint32_t MP_COLS = 32768;  // columns per minpos pass (128 KB of u32)
+
+template <bool USE_BPOS>
+__global__ __launch_bounds__(1024) void minpos_heavy_kernel(
+    const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const uint64_t* __restrict__ b_rp,
+    const uint32_t* __restrict__ b_col, const uint32_t* __restrict__ bpos, uint32_t rows_b, int cw_shift,
+    const uint32_t* __restrict__ rows_list, uint32_t n_rows, uint32_t* __restrict__ queue,
+    const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks, const uint32_t* __restrict__ hoff,
+    const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ col2, uint32_t* __restrict__ pos2) {
+  constexpr int TPB = 1024, SEG = 1024;
+  __shared__ uint32_t mp[MP_COLS];
+  __shared__ uint32_t seg_start[SEG + 1];
+  __shared__ uint32_t seg_lo[SEG];
+  __shared__ uint32_t seg_pos[SEG];  // stream position of the segment's first product
+  __shared__ uint32_t wsum[TPB / 64 + 1];
+  __shared__ uint32_t item_s;
+  for (uint32_t i = threadIdx.x; i < MP_COLS; i += TPB) mp[i] = 0xFFFFFFFFu;
+  const uint32_t cpg = MP_COLS >> cw_shift;  // numeric chunks per pass
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) item_s = atomicAdd(queue, 1u);
+    __syncthreads();
+    if (item_s >= n_rows) break;
+    const uint32_t row = rows_list[item_s];
+    const uint32_t hrow = hrow_of_row[row];
+    const uint32_t* ho = hoff + (uint64_t)hrow * nchunks;
+    const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
+    const uint64_t out_row = c_rp[row];
+    for (uint32_t j0 = 0; j0 < nchunks; j0 += cpg) {
+      const uint32_t j1 = j0 + cpg < nchunks ? j0 + cpg : nchunks;
+      const uint32_t c0 = j0 << cw_shift;
+      uint32_t carry = 0;  // products of the row's earlier A entries (all columns)
+      for (uint64_t pb = ps; pb < pe; pb += SEG) {
+        const uint64_t p = pb + threadIdx.x;
+        uint32_t lo = 0, len = 0, full = 0, skip = 0;
+        if (p < pe) {
+          const uint32_t k = a_col[p];
+          const uint32_t rs = (uint32_t)b_rp[k];
+          full = (uint32_t)b_rp[k + 1] - rs;
+          if (USE_BPOS) {
+            lo = bpos[(uint64_t)j0 * rows_b + k];
+            len = bpos[(uint64_t)j1 * rows_b + k] - lo;
+          } else {
+            lo = rs;
+            len = full;
+          }
+          skip = lo - rs;
+        }
+        const uint32_t before = block_excl_scan<TPB>(full, wsum);
+        __syncthreads();
+        const uint32_t batch_full = wsum[TPB / 64];
+        const uint32_t st = block_excl_scan<TPB>(len, wsum);
+        seg_start[threadIdx.x] = st;
+        seg_lo[threadIdx.x] = lo;
+        seg_pos[threadIdx.x] = carry + before + skip;
+        __syncthreads();
+        const uint32_t total = wsum[TPB / 64];
+        if (threadIdx.x == 0) seg_start[SEG] = total;
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < total; idx += TPB) {
+          const uint32_t sg = seg_find(seg_start, SEG, idx);
+          const uint32_t off = idx - seg_start[sg];
+          const uint32_t c = b_col[seg_lo[sg] + off] - c0;
+          if (c < MP_COLS && c < ((j1 - j0) << cw_shift)) atomicMin(&mp[c], seg_pos[sg] + off);
+        }
+        carry += batch_full;
+        __syncthreads();
+      }
+      // drain in column order: thread t owns 32 consecutive columns; untouched = 0xFFFFFFFF
+      uint32_t n = 0;
+      for (int j = 0; j < (int)(MP_COLS / TPB); ++j) n += mp[threadIdx.x * (MP_COLS / TPB) + j] != 0xFFFFFFFFu;
+      const uint32_t ex = block_excl_scan<TPB>(n, wsum);
+      if (n) {
+        uint64_t out = out_row + ho[j0] + ex;
+        for (int j = 0; j < (int)(MP_COLS / TPB); ++j) {
+          const uint32_t c = threadIdx.x * (MP_COLS / TPB) + j;
+          const uint32_t v = mp[c];
+          if (v != 0xFFFFFFFFu) {
+            col2[out] = c0 + c;
+            pos2[out] = v;
+            mp[c] = 0xFFFFFFFFu;
+            ++out;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(1024) void ref_order_long_kernel(const uint32_t* __restrict__ rows_list, uint32_t n_rows,
+                                                             uint32_t* __restrict__ queue,
+                                                             const uint64_t* __restrict__ c_rp,
+                                                             const uint32_t* __restrict__ col2,
+                                                             const uint32_t* __restrict__ pos2,
+                                                             uint32_t* __restrict__ c_col, T* __restrict__ c_val,
+                                                             unsigned long long* __restrict__ t2_all, uint64_t cap_max,
+                                                             uint32_t* __restrict__ scol_all, T* __restrict__ sval_all,
+                                                             uint64_t n_max) {
+  constexpr int TPB = 1024;
+  __shared__ uint32_t wsum[TPB / 64 + 1];
+  __shared__ uint32_t item_s;
+  unsigned long long* t2 = t2_all + (uint64_t)blockIdx.x * cap_max;
+  uint32_t* scol = scol_all + (uint64_t)blockIdx.x * n_max;
+  T* sval = sval_all + (uint64_t)blockIdx.x * n_max;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) item_s = atomicAdd(queue, 1u);
+    __syncthreads();
+    if (item_s >= n_rows) break;
+    const uint32_t row = rows_list[item_s];
+    const uint64_t out0 = c_rp[row];
+    const uint32_t n = (uint32_t)(c_rp[row + 1] - out0);
+    const uint32_t cap = table_size_for(n), mask = cap - 1;
+    for (uint32_t i = threadIdx.x; i < cap; i += TPB) __hip_atomic_store(&t2[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    // priority insertion (see ref_order_kernel), global 64-bit atomicMax
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      const uint32_t key = col2[out0 + i];
+      unsigned long long v = ((unsigned long long)(~pos2[out0 + i]) << 32) | key;
+      uint32_t h = (key * HASH_SCAL) & mask;
+      for (;;) {
+        const unsigned long long old = atomicMax(&t2[h], v);
+        if (old == 0ull) break;
+        if (old < v) v = old;
+        h = (h + 1) & mask;
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    // rank the occupied slots: thread t owns a contiguous range; slot becomes (rank + 1) << 32 | key
+    const uint32_t per = (cap + TPB - 1) / TPB;
+    const uint32_t s0 = threadIdx.x * per, s1 = s0 + per < cap ? s0 + per : cap;
+    uint32_t cnt = 0;
+    for (uint32_t sl = s0; sl < s1; ++sl)
+      cnt += __hip_atomic_load(&t2[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+    uint32_t r = block_excl_scan<TPB>(cnt, wsum);
+    for (uint32_t sl = s0; sl < s1; ++sl) {
+      const unsigned long long v = __hip_atomic_load(&t2[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v != 0ull) {
+        __hip_atomic_store(&t2[sl], ((unsigned long long)(r + 1) << 32) | (uint32_t)v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        ++r;
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      const uint32_t key = c_col[out0 + i];
+      uint32_t h = (key * HASH_SCAL) & mask;
+      unsigned long long v;
+      for (;;) {
+        v = __hip_atomic_load(&t2[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0ull && (uint32_t)v == key) break;
+        h = (h + 1) & mask;
+      }
+      const uint32_t rr = (uint32_t)(v >> 32) - 1;
+      __hip_atomic_store(&scol[rr], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sval[rr] = c_val[out0 + i];
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      c_col[out0 + i] = __hip_atomic_load(&scol[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c_val[out0 + i] = __builtin_nontemporal_load(&sval[i]);
+    }
+    __threadfence();
+  }
+}
+
+__global__ __launch_bounds__(256) void max_nnz_kernel(const uint32_t* __restrict__ list, uint32_t n,
+                                                     const uint32_t* __restrict__ row_nnz, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t v = i < n ? row_nnz[list[i]] : 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d, 64));
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
+
 }  // namespace spam
 
 // ---- plan ---------------------------------------------------------------------------------------------
@@ -1483,10 +1672,6 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
   SPAM_TRY((launch_num_row<T, 1024, 8192>(a, b, L + 3ull * rows, hc[3], rn, crp, cc, cv, s)));
 
   const uint32_t n_hnum = hc[NNUM - 1];
-  if (sort_rows == 2 && n_hnum)
-    return set_error(SPAM_E_UNSUPPORTED,
-                     "reference slot order (sort_rows = 2) is built in LDS and serves rows of at most 4096 entries; "
-                     "%u rows of this product are longer", n_hnum);
   if (n_hnum) {
     const char* dbg_env = getenv("SPAM_DBG_HEAVY");  // 32: print in-kernel phase timers (results unaffected)
     const int dbg_heavy = dbg_env ? atoi(dbg_env) : 0;
@@ -1539,8 +1724,47 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
               hg[4], hg[5], hg[6], hg[7], hg[8], hg[9], hg[10]);
     st.heavy_dense_groups = hg[0], st.heavy_hash_groups = hg[1], st.heavy_dense_nnz = hg[2], st.heavy_hash_nnz = hg[3];
   }
+  if (sort_rows == 2 && n_hnum) {
+    // long rows: first-occurrence positions chunk by chunk, then the reference-layout table in HBM
+    const uint32_t* hl = L + (uint64_t)(NNUM - 1) * rows;
+    DevBuf aux, col2, pos2, t2, scol, sval;
+    SPAM_TRY(aux.alloc(16));
+    SPAM_HIP_TRY(hipMemsetAsync(aux.p, 0, 16, s));
+    uint32_t* d_aux = aux.as<uint32_t>();  // [0] max nnz, [1] queue of pass 1, [2] queue of pass 2
+    max_nnz_kernel<<<(n_hnum + 255) / 256, 256, 0, s>>>(hl, n_hnum, rn, d_aux);
+    SPAM_CHECK_LAUNCH();
+    uint32_t nmax = 0;
+    SPAM_HIP_TRY(hipMemcpyAsync(&nmax, d_aux, 4, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+    uint64_t np2 = 1;
+    while (np2 < nmax) np2 <<= 1;
+    const uint64_t cap_max = std::max<uint64_t>(16, 2 * np2);  // the reference's capacity of the longest row
+    const uint64_t per_wg = cap_max * 8 + (uint64_t)nmax * (4 + sizeof(T));
+    const uint32_t nwg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(n_hnum, 512), (16ull << 30) / per_wg));
+    SPAM_TRY(col2.alloc(st.nnz_c * 4));
+    SPAM_TRY(pos2.alloc(st.nnz_c * 4));
+    SPAM_TRY(t2.alloc((uint64_t)nwg * cap_max * 8));
+    SPAM_TRY(scol.alloc((uint64_t)nwg * nmax * 4));
+    SPAM_TRY(sval.alloc((uint64_t)nwg * nmax * sizeof(T)));
+    const unsigned g1 = std::min<uint32_t>(n_hnum, HEAVY_GRID);
+    if (p->use_bpos)
+      minpos_heavy_kernel<true><<<g1, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, p->bpos.as<uint32_t>(),
+                                                    (uint32_t)b->rows, p->cw_shift, hl, n_hnum, d_aux + 1,
+                                                    p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hoff.as<uint32_t>(), crp,
+                                                    col2.as<uint32_t>(), pos2.as<uint32_t>());
+    else
+      minpos_heavy_kernel<false><<<g1, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, nullptr,
+                                                     (uint32_t)b->rows, p->cw_shift, hl, n_hnum, d_aux + 1,
+                                                     p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hoff.as<uint32_t>(), crp,
+                                                     col2.as<uint32_t>(), pos2.as<uint32_t>());
+    SPAM_CHECK_LAUNCH();
+    ref_order_long_kernel<T><<<nwg, 1024, 0, s>>>(hl, n_hnum, d_aux + 2, crp, col2.as<uint32_t>(), pos2.as<uint32_t>(), cc, cv,
+                                                  t2.as<unsigned long long>(), cap_max, scol.as<uint32_t>(), sval.as<T>(), nmax);
+    SPAM_CHECK_LAUNCH();
+    SPAM_HIP_TRY(hipStreamSynchronize(s));  // scratch goes back to the pool at scope exit
+  }
   if (sort_rows == 2) {
-    // reference slot order: every non-empty row has at most 4096 entries here (checked above)
+    // rows of at most 4096 entries: everything in LDS
     for (int bin = 0; bin < NNUM - 1; ++bin) {
       if (!hc[bin]) continue;
       ref_order_kernel<T><<<std::min<uint32_t>(hc[bin], 8192), 1024, 0, s>>>(

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no binaries (they are git-ignored): build the product and the checker once
+    lib = os.path.join(ROOT, "sparse_matrix_amd", "libspam_hip.so")
+    orc = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(orc)):
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")

@@ -280,9 +280,13 @@ def test_reference_slot_order_property_small_random(spam, oracle):
         assert C.invariants()
 
 
-def test_reference_slot_order_refuses_long_rows(spam):
+def test_reference_slot_order_long_rows(spam, oracle):
+    """Rows beyond 4096 entries (table in HBM): R-MAT scale 13 (one chunk pass), scale 16 (65 536 columns, rows of
+    up to 37 k entries, several passes, B pre-split), and an unsorted B (filter path) — col_idx bit-exact."""
     m = synth.rmat(13)
-    A, _ = _mk(spam, m)
-    with pytest.raises(spam.SpamError) as e:
-        A.mul_hash(A, reference_order=True)
-    assert e.value.code == 6
+    C = _exact_unsorted(spam, oracle, m, m)
+    assert np.diff(C.offsets.astype(np.int64)).max() > 4096
+    m = synth.rmat(16)
+    _exact_unsorted(spam, oracle, m, m)
+    _exact_unsorted(spam, oracle, synth.random_csr(8, 300, 0.6, seed=21, signed=False),
+                    synth.random_csr(300, 40_000, 0.05, seed=22, signed=False, sort_rows=False), b_sorted=False)
