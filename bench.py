@@ -282,7 +282,20 @@ def main():
                 sg["parity_sample"] = "ok: row_ptr exact, per-row column sets equal, values within 1e-10 (rows [%d,%d))" % (mid, r1)
             except AssertionError as ex:
                 sg["parity_sample"] = f"FAILED: {ex}"
-            log(f"[spgemm] cpu port sample {cpu_s:.1f}s on {cores} threads -> {sg['cpu_baseline']['value']} Mnnz/s; parity {sg['parity_sample']}")
+            # the same sample rows in the reference's slot order (sort_rows = 2): col_idx must be bit-identical
+            try:
+                B1 = DeviceCsr.from_torch(n, n, blk.row_ptr, blk.col_idx, blk.vals, True)
+                C2, _ = B1.row_block(mid, r1).spgemm(B1, sort_rows=2)
+                o2, i2, v2 = C2.download()
+                C2.free()
+                okc = bool(np.array_equal(o2, wo) and np.array_equal(i2, wi))
+                relv = float(np.max(np.abs(v2 - wv) / np.abs(wv))) if len(wv) else 0.0
+                sg["parity_sample_reference_order"] = (f"{'ok' if okc and relv <= 1e-10 else 'FAILED'}: row_ptr and unsorted col_idx "
+                                                       f"bit-identical to the oracle's linprobe slot order = {okc}, max rel value err {relv:.2e}")
+            except Exception as ex:  # noqa: BLE001
+                sg["parity_sample_reference_order"] = f"FAILED: {ex}"
+            log(f"[spgemm] cpu port sample {cpu_s:.1f}s on {cores} threads -> {sg['cpu_baseline']['value']} Mnnz/s; parity {sg['parity_sample']}; "
+                f"reference order {sg['parity_sample_reference_order']}")
         out["spgemm"] = sg
         if "metric" not in out:  # --no-spmv: promote the SpGEMM line
             out = {**{k: sg[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "scaling")}, "warmup": 1,
