@@ -528,7 +528,8 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
                                                         const uint64_t* __restrict__ b_rp,
                                                         const uint32_t* __restrict__ b_col,
                                                         const uint32_t* __restrict__ bpos, uint32_t rows_b,
-                                                        const uint32_t* __restrict__ heavy_rows, uint32_t n_heavy,
+                                                        const uint32_t* __restrict__ heavy_rows /* heaviest first */,
+                                                        uint32_t n_heavy, const uint32_t* __restrict__ hrow_of_row,
                                                         uint32_t nchunks, int cw_shift, uint32_t* __restrict__ hcnt,
                                                         uint32_t* __restrict__ queue) {
   constexpr int SEG = 1024;
@@ -548,9 +549,9 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
     __syncthreads();
     if (threadIdx.x == 0) item_s = atomicAdd(queue, 1u);
     __syncthreads();
-    const uint32_t hrow = item_s;
-    if (hrow >= n_heavy) break;
-    const uint32_t row = heavy_rows[hrow];
+    if (item_s >= n_heavy) break;
+    const uint32_t row = heavy_rows[item_s];
+    const uint32_t hrow = hrow_of_row[row];
     const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
     const bool cached = (pe - ps) <= SEG;
     if (cached && ps + threadIdx.x < pe) klist[threadIdx.x] = a_col[ps + threadIdx.x];
@@ -755,6 +756,47 @@ __global__ __launch_bounds__(256) void split_giant_kernel(const uint32_t* __rest
     else
       normal[bn + __popcll(mn & below)] = r;
   }
+}
+
+// Longest-first order for the work queues: rows are bucketed by floor(log2(F)) (64 buckets, heaviest bucket
+// first; order inside a bucket is unspecified).  A queue that ends on small rows has a short tail.
+__global__ __launch_bounds__(256) void cost_hist_kernel(const uint32_t* __restrict__ list, uint32_t n,
+                                                       const uint64_t* __restrict__ cost, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[64];
+  if (threadIdx.x < 64) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&h[63 - (63 - __clzll(cost[list[i]] | 1ull))], 1u);  // bucket 0 = largest costs
+  __syncthreads();
+  if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void cost_scan_kernel(uint32_t* __restrict__ hist /* [64] -> exclusive prefix */) {
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int b = 0; b < 64; ++b) {
+      const uint32_t c = hist[b];
+      hist[b] = run;
+      run += c;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void cost_scatter_kernel(const uint32_t* __restrict__ list, uint32_t n,
+                                                          const uint64_t* __restrict__ cost, uint32_t* __restrict__ cursor,
+                                                          uint32_t* __restrict__ out) {
+  __shared__ uint32_t h[64], base[64];
+  if (threadIdx.x < 64) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t r = 0, b = 0, rank = 0;
+  if (i < n) {
+    r = list[i];
+    b = 63 - (63 - __clzll(cost[r] | 1ull));
+    rank = atomicAdd(&h[b], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+  __syncthreads();
+  if (i < n) out[base[b] + rank] = r;
 }
 
 // Numeric pass for heavy rows: one workgroup per row.  The row's numeric chunks are grouped on the fly:
@@ -1492,6 +1534,20 @@ static int launch_num_hash(const spam_csr* a, const spam_csr* b, const uint32_t*
   return SPAM_OK;
 }
 
+// out = list reordered heaviest-first by cost[row]; tmp64 is a zeroed u32[64] scratch
+static int order_by_cost(const uint32_t* list, uint32_t n, const uint64_t* cost, uint32_t* tmp64, uint32_t* out,
+                         hipStream_t s) {
+  if (!n) return SPAM_OK;
+  SPAM_HIP_TRY(hipMemsetAsync(tmp64, 0, 64 * 4, s));
+  cost_hist_kernel<<<(n + 255) / 256, 256, 0, s>>>(list, n, cost, tmp64);
+  SPAM_CHECK_LAUNCH();
+  cost_scan_kernel<<<1, 64, 0, s>>>(tmp64);
+  SPAM_CHECK_LAUNCH();
+  cost_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>(list, n, cost, tmp64, out);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
 template <int TPB, int TABLE>
 static int launch_sym_row(const spam_csr* a, const spam_csr* b, const uint64_t* flops, const uint32_t* list, uint32_t n,
                           uint32_t* row_nnz, hipStream_t s) {
@@ -1603,14 +1659,20 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     SPAM_TRY(p->hcnt.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
     SPAM_TRY(p->hoff.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
     const unsigned grid = std::min<uint32_t>(p->n_heavy, HEAVY_GRID);  // gridDim.x * 1024 must stay below 2^32
+    DevBuf sym_order, otmp;
+    SPAM_TRY(sym_order.alloc((uint64_t)p->n_heavy * 4));
+    SPAM_TRY(otmp.alloc(64 * 4));
+    SPAM_TRY(order_by_cost(p->heavy_rows.as<uint32_t>(), p->n_heavy, fl, otmp.as<uint32_t>(), sym_order.as<uint32_t>(), s));
     if (p->use_bpos)
       sym_heavy_kernel<true><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, p->bpos.as<uint32_t>(),
-                                                   (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
-                                                   p->cw_shift, p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
+                                                   (uint32_t)b->rows, sym_order.as<uint32_t>(), p->n_heavy,
+                                                   p->hrow_of_row.as<uint32_t>(), p->nchunks, p->cw_shift,
+                                                   p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
     else
       sym_heavy_kernel<false><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, nullptr,
-                                                    (uint32_t)b->rows, p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
-                                                    p->cw_shift, p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
+                                                    (uint32_t)b->rows, sym_order.as<uint32_t>(), p->n_heavy,
+                                                    p->hrow_of_row.as<uint32_t>(), p->nchunks, p->cw_shift,
+                                                    p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
     SPAM_CHECK_LAUNCH();
     heavy_finalize_kernel<<<(p->n_heavy + 3) / 4, 256, 0, s>>>(p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
                                                               p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn);
@@ -1688,6 +1750,11 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     uint32_t hsplit[2];
     SPAM_HIP_TRY(hipMemcpyAsync(hsplit, qcnt, 8, hipMemcpyDeviceToHost, s));
     SPAM_HIP_TRY(hipStreamSynchronize(s));
+    DevBuf ordered, otmp;
+    SPAM_TRY(ordered.alloc((uint64_t)std::max<uint32_t>(hsplit[0], 1) * 4));
+    SPAM_TRY(otmp.alloc(64 * 4));
+    SPAM_TRY(order_by_cost(l_normal, hsplit[0], p->flops.as<uint64_t>(), otmp.as<uint32_t>(), ordered.as<uint32_t>(), s));
+    l_normal = ordered.as<uint32_t>();
 #define SPAM_NUM_HEAVY_G(BPOS_, SORT_, TPB_, CWS_, LIST_, N_, PARTS_, Q_)                                          \
   num_heavy_kernel<T, BPOS_, SORT_, TPB_, CWS_><<<std::min<uint32_t>((N_) * (PARTS_), HEAVY_GRID), TPB_, 0, s>>>( \
       a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals,                      \
