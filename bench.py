@@ -196,8 +196,8 @@ def main():
             rp, col, val = spdist.allgather_csr(blk.row_ptr, blk.col_idx, blk.vals, n, rank, world, dist)
             B = DeviceCsr.from_torch(n, n, rp, col, val, True)
             if world > 1:
-                flops, _ = B.rows_to_parts(B, world)  # rows_to_threads' flop count (mul_hash.rs:39-50)
-                offs = spdist.balanced_row_blocks(flops.astype(np.int64), world)  # its partition rule on F + row cost
+                # rows_to_threads' flop count and partition rule (mul_hash.rs:39-62) on F + a per-row cost, on the device
+                offs = B.balanced_row_blocks(B, world, spdist.ROW_OVERHEAD_PRODUCTS)
                 mylo, myhi = int(offs[rank]), int(offs[rank + 1])
                 if myhi <= mylo:
                     return None, None

@@ -77,6 +77,7 @@ SYMBOLS = {
     "spam_spgemm_plan_free": (None, [_P]),
     "spam_spgemm_dev": (C.c_int, [_P, _P, C.c_int, _PP, C.POINTER(SpgemmStats)]),
     "spam_rows_to_parts": (C.c_int, [_P, _P, _U64, _P, _P]),
+    "spam_rows_to_parts_weighted": (C.c_int, [_P, _P, _U64, _U64, _P]),
 }
 
 _lib = None

@@ -135,6 +135,12 @@ class DeviceCsr:
         check(_lib.load().spam_rows_to_parts(self._h, rhs._h, nparts, _vp(flops), _vp(offs)))
         return flops, offs
 
+    def balanced_row_blocks(self, rhs: "DeviceCsr", nparts: int, row_overhead: int = 2300) -> list:
+        """Contiguous row blocks balanced by F + row_overhead per non-empty row, computed on the device."""
+        offs = np.empty(nparts + 1, dtype=np.uint64)
+        check(_lib.load().spam_rows_to_parts_weighted(self._h, rhs._h, nparts, row_overhead, _vp(offs)))
+        return [int(v) for v in offs]
+
     def free(self):
         if self._h:
             _lib.load().spam_csr_free(self._h)

@@ -1459,6 +1459,39 @@ __global__ __launch_bounds__(256) void max_nnz_kernel(const uint32_t* __restrict
   if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
 
+// ---- rows_to_threads' partition on the device (mul_hash.rs:51-62) ---------------------------------------
+__global__ void part_cost_kernel(const uint64_t* __restrict__ flops, uint64_t rows, uint64_t row_overhead,
+                                 uint64_t* __restrict__ cost) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) cost[i] = flops[i] + (flops[i] ? row_overhead : 0);
+}
+// offsets[t] = partition_point(ps, x <= average * t) - 1 for t = 1..nparts-1; offsets[0] = 0, offsets[nparts] = rows
+__global__ void part_points_kernel(const uint64_t* __restrict__ ps, uint64_t rows, uint64_t nparts,
+                                   uint64_t* __restrict__ offsets) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > nparts) return;
+  if (t == 0) {
+    offsets[0] = 0;
+    return;
+  }
+  if (t == nparts) {
+    offsets[t] = rows;
+    return;
+  }
+  const uint64_t total = ps[rows];
+  const uint64_t avg = total / nparts + (total % nparts != 0);
+  const uint64_t bound = avg * t;
+  uint64_t lo = 0, hi = rows + 1;  // first index with ps[idx] > bound
+  while (lo < hi) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if (ps[mid] <= bound)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  offsets[t] = lo - 1;
+}
+
 }  // namespace spam
 
 // ---- plan ---------------------------------------------------------------------------------------------
@@ -1946,37 +1979,43 @@ int spam_spgemm_dev(const spam_csr* a, const spam_csr* b, int sort_rows, spam_cs
   return e;
 }
 
-int spam_rows_to_parts(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t* row_flops_out,
-                       uint64_t* rows_offset_out) {
+static int rows_to_parts_impl(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t row_overhead,
+                              uint64_t* row_flops_out, uint64_t* rows_offset_out) {
   clear_error();
   if (!rows_offset_out || nparts == 0) return set_error(SPAM_E_INVALID, "bad nparts / NULL output");
   SPAM_TRY(check_pair(a, b));
   hipStream_t s = stream();
-  DevBuf flops, total;
+  DevBuf flops, total, cost, ps, tmp, offs;
   SPAM_TRY(flops.alloc(a->rows * 8));
   SPAM_TRY(total.alloc(16));
   SPAM_TRY(launch_flops(a, b, flops.as<uint64_t>(), total.as<unsigned long long>(), s));
-  std::vector<uint64_t> f(a->rows);
+  SPAM_TRY(cost.alloc(a->rows * 8));
+  SPAM_TRY(ps.alloc((a->rows + 1) * 8));
+  SPAM_TRY(tmp.alloc(scan_tmp_bytes(a->rows)));
+  SPAM_TRY(offs.alloc((nparts + 1) * 8));
+  part_cost_kernel<<<(unsigned)((a->rows + 255) / 256), 256, 0, s>>>(flops.as<uint64_t>(), a->rows, row_overhead,
+                                                                      cost.as<uint64_t>());
+  SPAM_CHECK_LAUNCH();
+  SPAM_TRY(scan_u64_to_u64(cost.as<uint64_t>(), a->rows, ps.as<uint64_t>(), tmp.p, s));
+  part_points_kernel<<<(unsigned)((nparts + 1 + 63) / 64), 64, 0, s>>>(ps.as<uint64_t>(), a->rows, nparts, offs.as<uint64_t>());
+  SPAM_CHECK_LAUNCH();
   unsigned long long htot[2];
-  SPAM_HIP_TRY(hipMemcpyAsync(f.data(), flops.p, a->rows * 8, hipMemcpyDeviceToHost, s));
   SPAM_HIP_TRY(hipMemcpyAsync(htot, total.p, 16, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(rows_offset_out, offs.p, (nparts + 1) * 8, hipMemcpyDeviceToHost, s));
+  if (row_flops_out) SPAM_HIP_TRY(hipMemcpyAsync(row_flops_out, flops.p, a->rows * 8, hipMemcpyDeviceToHost, s));
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (htot[1]) return set_error(SPAM_E_OVERFLOW, "intermediate-product count overflows usize (mul_hash.rs:47-48)");
-  if (row_flops_out) std::copy(f.begin(), f.end(), row_flops_out);
-  // mul_hash.rs:51-62: prefix sum, average = ceil(total / tnum), partition_point(ps, x <= average * tid) - 1
-  std::vector<uint64_t> ps(a->rows + 1);
-  ps[0] = 0;
-  for (uint64_t i = 0; i < a->rows; ++i) ps[i + 1] = ps[i] + f[i];
-  const uint64_t tot = ps.back();
-  const uint64_t avg = tot / nparts + (tot % nparts != 0);
-  rows_offset_out[0] = 0;
-  for (uint64_t t = 1; t < nparts; ++t) {
-    const uint64_t bound = avg * t;
-    uint64_t pp = (uint64_t)(std::partition_point(ps.begin(), ps.end(), [&](uint64_t x) { return x <= bound; }) - ps.begin());
-    rows_offset_out[t] = pp - 1;
-  }
-  rows_offset_out[nparts] = a->rows;
   return SPAM_OK;
+}
+
+int spam_rows_to_parts(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t* row_flops_out,
+                       uint64_t* rows_offset_out) {
+  return rows_to_parts_impl(a, b, nparts, 0, row_flops_out, rows_offset_out);
+}
+
+int spam_rows_to_parts_weighted(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t row_overhead,
+                                uint64_t* rows_offset_out) {
+  return rows_to_parts_impl(a, b, nparts, row_overhead, nullptr, rows_offset_out);
 }
 
 }  // extern "C"

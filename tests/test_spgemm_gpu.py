@@ -153,6 +153,8 @@ def test_rows_to_parts_matches_oracle(spam, oracle):
         rn, ro = oracle.rows_to_threads(a[0], a[1], a[0], parts)
         assert np.array_equal(flops, rn) and np.array_equal(offs, ro)
         assert np.all(np.diff(offs.astype(np.int64)) >= 0) and offs[-1] == m.rows
+        from sparse_matrix_amd import dist as spdist
+        assert A.device().balanced_row_blocks(A.device(), parts, 2300) == spdist.balanced_row_blocks(rn.astype(np.int64), parts, 2300)
 
 
 def test_row_block_product_equals_slice(spam, oracle):
