@@ -89,6 +89,12 @@ int spam_csr_upload_f32(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64
 int spam_csr_from_device(int dtype, uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t* d_row_ptr,
                          const uint32_t* d_col_idx, const void* d_vals, int is_sorted, spam_csr** out);
 
+/* CSR from (row, col)-sorted triples already in HBM — the device-side `From<DokMatrix>` (BTreeMap order,
+ * spam_csr/src/lib.rs:315-334): builds row_ptr (owned by the handle), borrows d_col_idx / d_vals.
+ * SPAM_E_INVALID if the row indices are not non-decreasing or reach `rows`. */
+int spam_csr_from_sorted_coo(int dtype, uint64_t rows, uint64_t cols, uint64_t nnz, const uint32_t* d_row_idx,
+                             const uint32_t* d_col_idx, const void* d_vals, int is_sorted, spam_csr** out);
+
 /* A view of rows [row_lo, row_hi) of `a` as its own matrix (shares col_idx/vals with `a`, which must
  * outlive it).  Used to hand each GPU its row block of A (rows_to_threads with tnum = #GPUs). */
 int spam_csr_row_block(const spam_csr* a, uint64_t row_lo, uint64_t row_hi, spam_csr** out);

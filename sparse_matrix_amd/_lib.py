@@ -58,6 +58,7 @@ SYMBOLS = {
     "spam_csr_upload_f64": (C.c_int, [_U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
     "spam_csr_upload_f32": (C.c_int, [_U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
     "spam_csr_from_device": (C.c_int, [C.c_int, _U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
+    "spam_csr_from_sorted_coo": (C.c_int, [C.c_int, _U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
     "spam_csr_row_block": (C.c_int, [_P, _U64, _U64, _PP]),
     "spam_csr_dims": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64), C.POINTER(C.c_int),
                                 C.POINTER(C.c_int)]),

@@ -68,6 +68,20 @@ class DeviceCsr:
         return cls.from_device(dt, rows, cols, int(col_idx.numel()), row_ptr.data_ptr(), col_idx.data_ptr(),
                                vals.data_ptr(), is_sorted, keepalive=(row_ptr, col_idx, vals))
 
+    @classmethod
+    def from_sorted_coo_torch(cls, rows, cols, row_idx, col_idx, vals, is_sorted=True):
+        """(row, col)-sorted triples as torch CUDA tensors (int32 row_idx / col_idx): row_ptr is built on the device."""
+        import torch
+
+        assert row_idx.dtype == torch.int32 and col_idx.dtype == torch.int32
+        dt = SPAM_F64 if vals.dtype == torch.float64 else SPAM_F32
+        _lib.ensure_device()
+        h = C.c_void_p()
+        check(_lib.load().spam_csr_from_sorted_coo(dt, rows, cols, int(col_idx.numel()), C.c_void_p(row_idx.data_ptr()),
+                                                   C.c_void_p(col_idx.data_ptr()), C.c_void_p(vals.data_ptr()),
+                                                   int(bool(is_sorted)), C.byref(h)))
+        return cls(h, keepalive=(row_idx, col_idx, vals))
+
     def row_block(self, lo: int, hi: int) -> "DeviceCsr":
         h = C.c_void_p()
         check(_lib.load().spam_csr_row_block(self._h, lo, hi, C.byref(h)))

@@ -381,6 +381,43 @@ __global__ void rebase_row_ptr_kernel(const uint64_t* __restrict__ in, uint64_t*
   }
 }
 
+// row_ptr from the row indices of (row, col)-sorted triples: entry i opens rows (row[i-1], row[i]]
+__global__ void coo_row_ptr_kernel(const uint32_t* __restrict__ row, uint64_t nnz, uint64_t rows,
+                                   uint64_t* __restrict__ row_ptr, int* __restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nnz) return;
+  const uint64_t hi = i < nnz ? row[i] : rows;              // sentinel entry closes the trailing rows
+  const uint64_t lo = i == 0 ? 0 : (uint64_t)row[i - 1] + 1;  // first row not yet opened
+  if (i < nnz && (hi >= rows || (i > 0 && row[i] < row[i - 1]))) {
+    *bad = 1;
+    return;
+  }
+  for (uint64_t r = (i == 0 ? 0 : lo); r <= hi && r <= rows; ++r) row_ptr[r] = i;
+}
+
+int spam_csr_from_sorted_coo(int dtype, uint64_t rows, uint64_t cols, uint64_t nnz, const uint32_t* d_row_idx,
+                             const uint32_t* d_col_idx, const void* d_vals, int is_sorted, spam_csr** out) {
+  clear_error();
+  if (!out) return set_error(SPAM_E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (nnz && !d_row_idx) return set_error(SPAM_E_INVALID, "NULL device array");
+  hipStream_t s = stream();
+  DevBuf rp, bad;
+  SPAM_TRY(rp.alloc((rows + 1) * 8));
+  SPAM_TRY(bad.alloc(sizeof(int)));
+  SPAM_HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(int), s));
+  coo_row_ptr_kernel<<<(unsigned)((nnz + 1 + 255) / 256), 256, 0, s>>>(d_row_idx, nnz, rows, rp.as<uint64_t>(), bad.as<int>());
+  SPAM_CHECK_LAUNCH();
+  int h = 0;
+  SPAM_HIP_TRY(hipMemcpyAsync(&h, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  if (h) return set_error(SPAM_E_INVALID, "row indices are not sorted or >= rows");
+  SPAM_TRY(spam_csr_from_device(dtype, rows, cols, nnz, rp.as<uint64_t>(), d_col_idx, d_vals, is_sorted, out));
+  (*out)->row_ptr = (uint64_t*)rp.release();  // the handle owns the row_ptr it was built with
+  (*out)->owns_row_ptr = true;
+  return SPAM_OK;
+}
+
 int spam_csr_row_block(const spam_csr* a, uint64_t row_lo, uint64_t row_hi, spam_csr** out) {
   clear_error();
   if (!a || !out) return set_error(SPAM_E_INVALID, "NULL argument");

@@ -154,3 +154,23 @@ def test_cfg2_full_size_linearity_and_third_party(spam, oracle):
     yh = yx.cpu().numpy()
     m = yo != 0
     assert (np.abs(yh[m] - yo[m]) / np.abs(yo[m])).max() <= F64_RTOL and np.all(yh[~m] == 0)
+
+
+def test_device_csr_from_sorted_coo(spam, oracle):
+    """The device-side From<DokMatrix> (spam_csr/src/lib.rs:315-334): row_ptr from sorted (row, col) triples, with
+    empty leading / inner / trailing rows; same SpMV as the host-built matrix; unsorted rows are rejected."""
+    from sparse_matrix_amd import DeviceCsr
+
+    dev = torch.device("cuda", 0)
+    m = synth.rmat(11)
+    rows_of = torch.repeat_interleave(torch.arange(m.rows, dtype=torch.int32), (m.row_ptr[1:] - m.row_ptr[:-1]))
+    d = DeviceCsr.from_sorted_coo_torch(m.rows, m.cols, rows_of.to(dev), m.col_idx.to(dev), m.vals.to(dev))
+    assert d.invariants()
+    assert np.array_equal(d.download_row_ptr(), m.row_ptr.numpy().astype(np.uint64))
+    x = synth.dense_vector(m.cols).numpy()
+    ref = oracle.spmv(csr_np(m), x)
+    assert np.abs(d.spmv(x) - ref).max() <= F64_RTOL * np.abs(ref).max()
+    bad = rows_of.clone()
+    bad[5], bad[6] = 9, 3
+    with pytest.raises(spam.SpamError):
+        DeviceCsr.from_sorted_coo_torch(m.rows, m.cols, bad.to(dev), m.col_idx.to(dev), m.vals.to(dev))
