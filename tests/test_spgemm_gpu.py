@@ -71,6 +71,16 @@ def test_wide_b_many_symbolic_chunks(spam, oracle):
     _both(spam, oracle, ma, mb, F64_RTOL)
 
 
+def test_very_wide_b_several_bitmap_windows(spam, oracle):
+    """B with 2.5 M columns: 153 numeric chunks and 3 symbolic bitmap windows of 2^20 columns per heavy row, rows of
+    C with ~450 k entries; all three output orders."""
+    ma = synth.random_csr(6, 2000, 0.25, seed=41, signed=False)
+    mb = synth.random_csr(2000, 2_500_000, 0.0004, seed=42, signed=False)
+    C = _both(spam, oracle, ma, mb, F64_RTOL)
+    assert np.diff(C.offsets.astype(np.int64)).max() > 300_000
+    _exact_unsorted(spam, oracle, ma, mb)
+
+
 def test_unsorted_b_heavy_rows_filter_path(spam, oracle):
     """Unsorted B cannot be pre-split; heavy rows then filter every product by chunk."""
     ma = synth.random_csr(8, 300, 0.6, seed=21, signed=False)
@@ -175,14 +185,14 @@ def test_row_block_product_equals_slice(spam, oracle):
 
 
 def test_full_size_row_sum_property(spam):
-    """BASELINE-size check that needs no CPU product: (A*A)*1 == A*(A*1) row by row at R-MAT scale 19
-    (F = 7.9e9 products, nnz(C) = 3.5e9, beyond 2^31 work items on the heavy path), sorted and unsorted
-    output, plus invariants 1-7 of the sorted result on the device."""
+    """BASELINE configs[2] at full size (R-MAT scale 20: F = 2.09e10 products, nnz(C) = 9.7e9 > 2^32) with a check
+    that needs no CPU product: (A*A)*1 == A*(A*1) row by row, sorted and unsorted output, plus invariants 1-7 of
+    the sorted result on the device."""
     import torch
     from sparse_matrix_amd import DeviceCsr
 
     dev = torch.device("cuda", 0)
-    A = synth.rmat(19, dtype=torch.float64, device=dev)
+    A = synth.rmat(20, dtype=torch.float64, device=dev)
     dA = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, A.vals, True)
     ones = torch.ones(A.cols, dtype=torch.float64, device=dev)
     t1, t2, t3 = (torch.empty(A.rows, dtype=torch.float64, device=dev) for _ in range(3))
@@ -190,7 +200,7 @@ def test_full_size_row_sum_property(spam):
     dA.spmv_dev(t1.data_ptr(), t2.data_ptr())
     for sort_rows in (False, True):
         C, st = dA.spgemm(dA, sort_rows=sort_rows)
-        assert st["nnz_c"] > 3_000_000_000 and st["flops_f"] > 7_000_000_000
+        assert st["nnz_c"] > 9_000_000_000 and st["flops_f"] > 20_000_000_000
         C.spmv_dev(ones.data_ptr(), t3.data_ptr())
         torch.cuda.synchronize()
         rel = ((t3 - t2).abs() / t2.abs().clamp_min(1e-300)).max().item()

@@ -174,3 +174,22 @@ def test_device_csr_from_sorted_coo(spam, oracle):
     bad[5], bad[6] = 9, 3
     with pytest.raises(spam.SpamError):
         DeviceCsr.from_sorted_coo_torch(m.rows, m.cols, bad.to(dev), m.col_idx.to(dev), m.vals.to(dev))
+
+
+def test_cfg5_full_size_f32_powerlaw(spam, oracle):
+    """BASELINE configs[4] at full size: 2 M rows, 2000 rows of 50 000 entries among rows of 8 (115.98 M nnz), f32,
+    device-resident, against the f64-accumulated oracle at 1e-5 relative."""
+    from sparse_matrix_amd import DeviceCsr
+
+    dev = torch.device("cuda", 0)
+    A = synth.powerlaw(dtype=torch.float32, device=dev)
+    assert A.rows == 2_000_000 and A.nnz == 2000 * 50_000 + 1_998_000 * 8
+    dA = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, A.vals, True)
+    x = synth.dense_vector(A.cols, dtype=torch.float32, device=dev)
+    y = torch.empty(A.rows, dtype=torch.float32, device=dev)
+    dA.spmv_dev(x.data_ptr(), y.data_ptr())
+    torch.cuda.synchronize()
+    off, idx, val = A.cpu_numpy()
+    ref = oracle.spmv((off, idx, val.astype(np.float64)), x.cpu().numpy().astype(np.float64), nthreads=oracle.hardware_threads())
+    yh = y.cpu().numpy().astype(np.float64)
+    assert (np.abs(yh - ref) / np.abs(ref)).max() <= F32_RTOL
