@@ -265,6 +265,31 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void sym_hash_kernel(
 // lane has HEAVY_U independent loads in flight.
 constexpr int HEAVY_U = 8;
 
+// exclusive prefix + block total in every thread (two barriers, none needed afterwards to read the total)
+template <int TPB>
+__device__ __forceinline__ uint32_t block_excl_scan_tot(uint32_t v, uint32_t* wsum /* [TPB/64 + 1] */, uint32_t& total) {
+  constexpr int NW = TPB / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();  // wsum may still be read from the previous call
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const uint32_t c = wsum[i];
+    if (i < w) off += c;
+    tot += c;
+  }
+  total = tot;
+  return off + inc - v;
+}
+
 template <int TPB>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /* [TPB/64 + 1] */) {
   constexpr int NW = TPB / 64;
@@ -378,11 +403,10 @@ __global__ __launch_bounds__(TPB) void sym_row_kernel(const uint64_t* __restrict
         lo = (uint32_t)b_rp[k];
         len = (uint32_t)b_rp[k + 1] - lo;
       }
-      const uint32_t st = block_excl_scan<TPB>(len, wsum);
+      uint32_t total;
+      const uint32_t st = block_excl_scan_tot<TPB>(len, wsum, total);
       seg_start[threadIdx.x] = st;
       seg_lo[threadIdx.x] = lo;
-      __syncthreads();
-      const uint32_t total = wsum[TPB / 64];
       if (threadIdx.x == 0) seg_start[SEG] = total;
       __syncthreads();
       const uint32_t upl = total >= TPB * ROW_U ? ROW_U : (total + TPB - 1) / TPB;  // spread small rows over all waves
@@ -442,11 +466,10 @@ __global__ __launch_bounds__(TPB) void num_row_kernel(
         lo = (uint32_t)b_rp[k];
         len = (uint32_t)b_rp[k + 1] - lo;
       }
-      const uint32_t st = block_excl_scan<TPB>(len, wsum);
+      uint32_t total;
+      const uint32_t st = block_excl_scan_tot<TPB>(len, wsum, total);
       seg_start[threadIdx.x] = st;
       seg_lo[threadIdx.x] = lo;
-      __syncthreads();
-      const uint32_t total = wsum[TPB / 64];
       if (threadIdx.x == 0) seg_start[SEG] = total;
       __syncthreads();
       const uint32_t upl = total >= TPB * ROW_U ? ROW_U : (total + TPB - 1) / TPB;  // spread small rows over all waves
@@ -572,11 +595,10 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
             len = (uint32_t)b_rp[k + 1] - lo;
           }
         }
-        const uint32_t st = block_excl_scan_1024(len, wsum);
+        uint32_t total;
+        const uint32_t st = block_excl_scan_tot<1024>(len, wsum, total);
         seg_start[threadIdx.x] = st;
         seg_lo[threadIdx.x] = lo;
-        __syncthreads();
-        const uint32_t total = wsum[16];
         if (threadIdx.x == 0) seg_start[SEG] = total;
         __syncthreads();
         // each wavefront takes 64*HEAVY_U consecutive products per round, lane-contiguous inside every load
@@ -957,13 +979,12 @@ __global__ __launch_bounds__(TPB) void num_heavy_kernel(
           }
         }
         pf_g = g + parts;
-        const uint32_t st = block_excl_scan<TPB>(len, wsum);
+        uint32_t total;
+        const uint32_t st = block_excl_scan_tot<TPB>(len, wsum, total);
         if (threadIdx.x < SEG) {
           seg_start[threadIdx.x] = st;
           seg_lo[threadIdx.x] = lo;
         }
-        __syncthreads();
-        const uint32_t total = wsum[TPB / 64];
         if (threadIdx.x == 0) seg_start[SEG] = total;
         __syncthreads();
         if (timing) {
@@ -1203,11 +1224,10 @@ __global__ __launch_bounds__(1024) void ref_order_kernel(const uint64_t* __restr
         lo = (uint32_t)b_rp[k];
         len = (uint32_t)b_rp[k + 1] - lo;
       }
-      const uint32_t st = block_excl_scan<TPB>(len, wsum);
+      uint32_t total;
+      const uint32_t st = block_excl_scan_tot<TPB>(len, wsum, total);
       seg_start[threadIdx.x] = st;
       seg_lo[threadIdx.x] = lo;
-      __syncthreads();
-      const uint32_t total = wsum[TPB / 64];
       if (threadIdx.x == 0) seg_start[SEG] = total;
       __syncthreads();
       for (uint32_t idx = threadIdx.x; idx < total; idx += TPB) {
