@@ -2,26 +2,28 @@
 //
 // Reference counterpart: CsrMatrix::mul_hash (spam_csr/src/mul_hash.rs:13-201) with its linprobe
 // accumulator (linprobe/src/{lib,set,map}.rs):
-//   rows_to_threads  :38-64   -> spgemm_flops_kernel (+ host partition in spam_rows_to_parts)
-//   mul_hash_symbolic:66-103  -> sym_hash_kernel<G,S,TABLE> (LDS linprobe set, atomicCAS claim) and
-//                                sym_heavy_kernel (2^20-column bitmap windows in LDS, LDS atomic OR)
+//   rows_to_threads  :38-64   -> spgemm_flops_kernel; partition rule in part_points_kernel (spam_rows_to_parts*)
+//   mul_hash_symbolic:66-103  -> sym_hash_kernel (rows of <= 512 products, several rows per workgroup),
+//                                sym_row_kernel (<= 4096, one row per workgroup), sym_heavy_kernel (bitmap windows)
 //   checked_inclusive_scan (lib.rs:267-274) -> scan_u32_to_u64
-//   mul_hash_numeric :106-201 -> num_hash_kernel<T,G,S,TABLE> (LDS linprobe map: u32 keys + T values,
-//                                atomicCAS claim + LDS atomic add) and num_heavy_kernel (per row: dense T
-//                                accumulator over a 16384-column chunk, or one linprobe table shared by a
-//                                run of sparser chunks, both in LDS)
-//   B2 (sort rows)   :164-175 -> sort_rows_kernel (bitonic in LDS); heavy rows come out sorted anyway
+//   mul_hash_numeric :106-201 -> num_hash_kernel / num_row_kernel (LDS linprobe map: u32 keys + T values, atomicCAS
+//                                claim + LDS atomic add) and num_heavy_kernel (per row: dense T accumulator over a
+//                                16384-column chunk, or one table shared by a run of sparser chunks, both in LDS)
+//   B2 (sort rows)   :164-175 -> sort_rows_kernel (bitonic in LDS); heavy rows sort inside num_heavy_kernel
+//   linprobe slot order (map.rs:59-63) -> ref_order_kernel / minpos_heavy_kernel + ref_order_long_kernel (sort_rows = 2)
 //
-// Where the CPU code gives each thread a contiguous flop-balanced row range (mul_hash.rs:52-62), the GPU
-// bins rows by work: by F (intermediate products) for the symbolic pass, by nnz(C_i) for the numeric pass.
-// A bin fixes the lanes per row (16 / 64 / 256 / 1024) and the LDS table size, keeping linprobe's hash
-// (key * 107) & (size - 1), its sentinel u32::MAX and its sizing max(16, 2 * next_pow2(n)).
-// Rows whose table would not fit LDS take the "heavy" path: the column range is cut into chunks whose
-// dense accumulator does fit LDS, and B's sorted rows are pre-split at the chunk boundaries (bpos) so a
-// (row, chunk) work item touches only its own products.  No MFMA: nothing here is a dense contraction.
+// Where the CPU code gives each thread a contiguous flop-balanced row range (mul_hash.rs:52-62), the GPU bins rows
+// by work: by F (intermediate products) for the symbolic pass, by nnz(C_i) for the numeric pass.  A bin fixes the
+// lanes per row (16 / 64 / 256 / 1024) and the LDS table size; the hash bins keep linprobe's hash (key * 107) &
+// (size - 1), its sentinel u32::MAX and its sizing max(16, 2 * next_pow2(n)).  Rows whose table would not fit LDS
+// take the "heavy" path: the column range is cut into chunks, B's sorted rows are pre-split at the chunk boundaries
+// (bpos) so a chunk range touches only its own products, and a row's chunks are accumulated group by group in LDS.
+// All one-row-per-workgroup kernels walk the products the same way: the B segments of up to SEG entries of A's row
+// are prefix-summed in LDS and each wavefront takes 64*U consecutive products per round (lane-contiguous loads).
+// Heavy rows are pulled from device-wide queues, heaviest first.  No MFMA: nothing here is a dense contraction.
 //
-// Output order with sort_rows = 0: hash-path rows are emitted in THIS table's slot order (parallel claims
-// permute keys inside a collision run relative to the reference's sequential insertion), heavy rows sorted.
+// Output order: sort_rows = 0 this library's table order (hash rows: slot order of a table filled in parallel;
+// heavy rows: chunk group by chunk group), 1 sorted by column (B2), 2 the reference's exact linprobe slot order.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -31,8 +33,9 @@
 namespace spam {
 
 // ---- geometry -------------------------------------------------------------------------------------
-// numeric chunk width of the heavy path, chosen per product: 2^13 columns with 512-thread workgroups (80 KB of LDS,
-// two workgroups per CU overlap each other's latencies) when B has at most 4 M columns, else 2^14 with 1024 threads.
+// numeric chunk width of the heavy path: 2^14 columns with 1024-thread workgroups (157 KB of LDS, one per CU).  The
+// 2^13 / 512-thread geometry (80 KB, two per CU) exists for A/B runs (SPAM_HEAVY_TPB=512): it doubles the number of
+// chunk groups and measured 1.65x slower on R-MAT scale 20.
 constexpr int CW_SHIFT_SMALL = 13, CW_SHIFT_LARGE = 14;
 constexpr uint32_t MAXCH_SMALL = 512, MAXCH_LARGE = 1024;  // chunks per row the LDS group list can hold
 
