@@ -1473,10 +1473,16 @@ __global__ __launch_bounds__(1024) void ref_order_long_kernel(const uint32_t* __
   }
 }
 
+// out[0] = longest row of the list; out[3] = 1 if a row has 2^32 or more intermediate products
 __global__ __launch_bounds__(256) void max_nnz_kernel(const uint32_t* __restrict__ list, uint32_t n,
-                                                     const uint32_t* __restrict__ row_nnz, uint32_t* __restrict__ out) {
+                                                     const uint32_t* __restrict__ row_nnz,
+                                                     const uint64_t* __restrict__ flops, uint32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t v = i < n ? row_nnz[list[i]] : 0;
+  uint32_t v = 0;
+  if (i < n) {
+    v = row_nnz[list[i]];
+    if (flops[list[i]] >> 32) out[3] = 1;
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d, 64));
   if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
@@ -1854,11 +1860,14 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     SPAM_TRY(aux.alloc(16));
     SPAM_HIP_TRY(hipMemsetAsync(aux.p, 0, 16, s));
     uint32_t* d_aux = aux.as<uint32_t>();  // [0] max nnz, [1] queue of pass 1, [2] queue of pass 2
-    max_nnz_kernel<<<(n_hnum + 255) / 256, 256, 0, s>>>(hl, n_hnum, rn, d_aux);
+    max_nnz_kernel<<<(n_hnum + 255) / 256, 256, 0, s>>>(hl, n_hnum, rn, p->flops.as<uint64_t>(), d_aux);
     SPAM_CHECK_LAUNCH();
-    uint32_t nmax = 0;
-    SPAM_HIP_TRY(hipMemcpyAsync(&nmax, d_aux, 4, hipMemcpyDeviceToHost, s));
+    uint32_t haux[4] = {0, 0, 0, 0};
+    SPAM_HIP_TRY(hipMemcpyAsync(haux, d_aux, 16, hipMemcpyDeviceToHost, s));
     SPAM_HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t nmax = haux[0];
+    if (haux[3])
+      return set_error(SPAM_E_UNSUPPORTED, "reference slot order keeps 32-bit stream positions: a row has >= 2^32 products");
     uint64_t np2 = 1;
     while (np2 < nmax) np2 <<= 1;
     const uint64_t cap_max = std::max<uint64_t>(16, 2 * np2);  // the reference's capacity of the longest row
