@@ -302,3 +302,40 @@ def test_reference_slot_order_long_rows(spam, oracle):
     _exact_unsorted(spam, oracle, m, m)
     _exact_unsorted(spam, oracle, synth.random_csr(8, 300, 0.6, seed=21, signed=False),
                     synth.random_csr(300, 40_000, 0.05, seed=22, signed=False, sort_rows=False), b_sorted=False)
+
+
+def test_bin_and_group_boundaries(spam, oracle):
+    """Rows engineered to sit exactly on every internal threshold: F and nnz(C_i) of 64/65, 512/513, 2048/2049,
+    4096/4097 (bin edges), 3072/3073 and 6143/6144/6145 (dense threshold and hash-group capacity of the heavy
+    path), with columns straddling 16 384-column chunk edges; overlapping B rows make F > nnz.  All three orders."""
+    targets = [1, 2, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 3071, 3072, 3073, 4095, 4096, 4097, 6143, 6144, 6145,
+               9000, 16383, 16384, 16385, 40000]
+    cols = 70_000
+    b_rows = []
+    # B row 2t holds t_nnz consecutive columns starting just below a chunk edge; B row 2t+1 overlaps its first half
+    for t, n in enumerate(targets):
+        start = (16384 * (1 + t % 3) - n // 3) % (cols - n)
+        b_rows.append(np.arange(start, start + n))
+        b_rows.append(np.arange(start, start + max(1, n // 2)))
+    b_off = np.concatenate([[0], np.cumsum([len(r) for r in b_rows])]).astype(np.uint64)
+    b_idx = np.concatenate(b_rows).astype(np.uint64)
+    rng = np.random.default_rng(5)
+    b_val = rng.uniform(0.5, 1.5, b_idx.size)
+    # A row t references B rows 2t and 2t+1 (in that order), plus a last row referencing everything
+    a_rows = [[2 * t, 2 * t + 1] for t in range(len(targets))] + [list(range(2 * len(targets)))]
+    a_off = np.concatenate([[0], np.cumsum([len(r) for r in a_rows])]).astype(np.uint64)
+    a_idx = np.concatenate(a_rows).astype(np.uint64)
+    a_val = rng.uniform(0.5, 1.5, a_idx.size)
+    A = spam.CsrMatrix(len(a_rows), len(b_rows), a_val, a_idx, a_off, True)
+    B = spam.CsrMatrix(len(b_rows), cols, b_val, b_idx, b_off, True)
+    a, b = (a_off, a_idx, a_val), (b_off, b_idx, b_val)
+    want_s = oracle.mul_hash(a, b, sort_rows=True)
+    want_u = oracle.mul_hash(a, b, sort_rows=False)
+    assert np.diff(want_s[0].astype(np.int64))[:len(targets)].tolist() == targets
+    Cs = A.mul_hash(B, sort_output=True)
+    assert_csr_parity((Cs.offsets, Cs.indices, Cs.vals), want_s, True, F64_RTOL)
+    Ct = A.mul_hash(B, sort_output=False)
+    assert_csr_parity((Ct.offsets, Ct.indices, Ct.vals), want_u, False, F64_RTOL)
+    Cr = A.mul_hash(B, reference_order=True)
+    assert np.array_equal(Cr.offsets, want_u[0]) and np.array_equal(Cr.indices, want_u[1])
+    assert np.max(np.abs(Cr.vals - want_u[2]) / want_u[2]) <= F64_RTOL
