@@ -106,6 +106,9 @@ int spam_csr_device_ptrs(const spam_csr* m, const uint64_t** d_row_ptr, const ui
 /* Copy back into caller-allocated host Vecs (offsets[rows+1], indices[nnz] widened to usize, vals[nnz]). */
 int spam_csr_download_f64(const spam_csr* m, uint64_t* offsets, uint64_t* indices, double* vals);
 int spam_csr_download_f32(const spam_csr* m, uint64_t* offsets, uint64_t* indices, float* vals);
+/* Sort every row by column in place: CsrMatrix<T, false> -> CsrMatrix<T, true> (what `From<DokMatrix>` guarantees,
+ * spam_csr/src/lib.rs:315-334).  Only for handles that own their arrays (uploads, SpGEMM results). */
+int spam_csr_sort_rows(spam_csr* m);
 /* CsrMatrix::invariants() 1-7 evaluated on the device (spam_csr/src/lib.rs:47-81,152-160).  *ok = 0/1. */
 int spam_csr_invariants(const spam_csr* m, int* ok);
 void spam_csr_free(spam_csr* m);

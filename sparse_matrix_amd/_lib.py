@@ -65,6 +65,7 @@ SYMBOLS = {
     "spam_csr_device_ptrs": (C.c_int, [_P, _PP, _PP, _PP]),
     "spam_csr_download_f64": (C.c_int, [_P, _P, _P, _P]),
     "spam_csr_download_f32": (C.c_int, [_P, _P, _P, _P]),
+    "spam_csr_sort_rows": (C.c_int, [_P]),
     "spam_csr_invariants": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "spam_csr_free": (None, [_P]),
     "spam_spmv_f64": (C.c_int, [_P, _P, _P]),

@@ -99,6 +99,10 @@ class DeviceCsr:
         check(_lib.load().spam_csr_device_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def sort_rows(self):
+        """In-place per-row sort by column (the handle becomes IS_SORTED = true)."""
+        check(_lib.load().spam_csr_sort_rows(self._h))
+
     def invariants(self) -> bool:
         ok = C.c_int()
         check(_lib.load().spam_csr_invariants(self._h, C.byref(ok)))

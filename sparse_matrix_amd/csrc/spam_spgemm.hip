@@ -1521,6 +1521,83 @@ __global__ void part_points_kernel(const uint64_t* __restrict__ ps, uint64_t row
   offsets[t] = lo - 1;
 }
 
+// ---- sort the rows of a CSR matrix by column (CsrMatrix<T, false> -> CsrMatrix<T, true>) -----------------
+// Rows of up to 4096 entries: sort_rows_kernel (bitonic in LDS).  Longer rows: scatter into a dense 16384-column
+// window (value + byte flag per column, entries of a row are distinct), drain the window in column order into a
+// staging slab, copy back.  One workgroup per long row, cols / 16384 passes over the row.
+__global__ __launch_bounds__(256) void row_len_kernel(const uint64_t* __restrict__ rp, uint32_t rows,
+                                                     uint32_t* __restrict__ len) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) {
+    const uint64_t l = rp[r + 1] - rp[r];
+    len[r] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(1024) void sort_long_rows_kernel(const uint32_t* __restrict__ rows_list, uint32_t n_rows,
+                                                             uint32_t* __restrict__ queue,
+                                                             const uint64_t* __restrict__ rp, uint32_t* __restrict__ col,
+                                                             T* __restrict__ val, uint64_t ncols,
+                                                             uint32_t* __restrict__ scol_all, T* __restrict__ sval_all,
+                                                             uint64_t n_max) {
+  constexpr int TPB = 1024;
+  constexpr uint32_t W = 16384;
+  __shared__ __attribute__((aligned(16))) T acc[W];
+  __shared__ __attribute__((aligned(16))) uint8_t flags[W];
+  __shared__ uint32_t wsum[TPB / 64 + 1];
+  __shared__ uint32_t item_s;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4* f4 = (u32x4*)flags;
+  f4[threadIdx.x] = (u32x4)(0u);
+  uint32_t* scol = scol_all + (uint64_t)blockIdx.x * n_max;
+  T* sval = sval_all + (uint64_t)blockIdx.x * n_max;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) item_s = atomicAdd(queue, 1u);
+    __syncthreads();
+    if (item_s >= n_rows) break;
+    const uint32_t row = rows_list[item_s];
+    const uint64_t s0 = rp[row];
+    const uint32_t n = (uint32_t)(rp[row + 1] - s0);
+    uint32_t done = 0;
+    for (uint64_t c0 = 0; c0 < ncols && done < n; c0 += W) {
+      for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+        const uint64_t c = (uint64_t)col[s0 + i] - c0;
+        if (c < W) {
+          acc[c] = val[s0 + i];
+          flags[c] = 1;
+        }
+      }
+      __syncthreads();
+      const u32x4 w = f4[threadIdx.x];
+      const uint32_t cnt = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+      uint32_t tot;
+      uint32_t out = done + block_excl_scan_tot<TPB>(cnt, wsum, tot);
+      if (cnt) {
+        f4[threadIdx.x] = (u32x4)(0u);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if ((ww[j >> 2] >> ((j & 3) * 8)) & 1u) {
+            scol[out] = (uint32_t)(c0 + threadIdx.x * 16 + j);
+            sval[out] = acc[threadIdx.x * 16 + j];
+            ++out;
+          }
+      }
+      done += tot;
+      __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      col[s0 + i] = __builtin_nontemporal_load(&scol[i]);
+      val[s0 + i] = __builtin_nontemporal_load(&sval[i]);
+    }
+    __threadfence();
+  }
+}
+
 }  // namespace spam
 
 // ---- plan ---------------------------------------------------------------------------------------------
@@ -1532,6 +1609,9 @@ struct spam_spgemm_plan {
   spam::DevBuf hrow_of_row;  // u32[rows]: index into heavy_rows
   spam::DevBuf hcnt, hoff;   // u32[n_heavy * nchunks]
   spam::DevBuf bpos;         // u32[(nchunks + 1) * rows_b]
+  spam::DevBuf bs_col, bs_val;  // row-sorted copy of an unsorted B (heavy path only)
+  const uint32_t* b_col = nullptr;  // B's arrays as the heavy kernels see them
+  const void* b_val = nullptr;
   uint32_t n_heavy = 0, nchunks = 0;
   int cw_shift = spam::CW_SHIFT_LARGE;
   bool use_bpos = false;
@@ -1642,6 +1722,57 @@ static int launch_sort(const uint32_t* list, uint32_t n, const uint64_t* c_rp, u
   return SPAM_OK;
 }
 
+// Sort rows [in place] of arrays (rp, col, val).  `max_hint` 0 = unknown.
+template <class T>
+static int sort_rows_typed(uint64_t rows64, uint64_t cols, const uint64_t* rp, uint32_t* col, T* val, hipStream_t s) {
+  const uint32_t rows = (uint32_t)rows64;
+  DevBuf len, counts, lists, aux;
+  SPAM_TRY(len.alloc((uint64_t)rows * 4));
+  SPAM_TRY(counts.alloc(16 * 4));
+  SPAM_TRY(lists.alloc((uint64_t)NNUM * rows * 4));
+  SPAM_HIP_TRY(hipMemsetAsync(counts.p, 0, 64, s));
+  row_len_kernel<<<(rows + 255) / 256, 256, 0, s>>>(rp, rows, len.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  BinLimits lim{};
+  lim.nbins = NNUM;
+  for (int i = 0; i < NNUM - 1; ++i) lim.max[i] = NUM_MAX[i];
+  bin_rows_kernel<uint32_t><<<(rows + 255) / 256, 256, 0, s>>>(len.as<uint32_t>(), rows, lim, counts.as<uint32_t>(),
+                                                              lists.as<uint32_t>(), nullptr);
+  SPAM_CHECK_LAUNCH();
+  uint32_t hc[8];
+  SPAM_HIP_TRY(hipMemcpyAsync(hc, counts.p, 32, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  const uint32_t* L = lists.as<uint32_t>();
+  SPAM_TRY((launch_sort<T, 16, 64>(L + 0ull * rows, hc[0], rp, col, val, s)));
+  SPAM_TRY((launch_sort<T, 64, 512>(L + 1ull * rows, hc[1], rp, col, val, s)));
+  SPAM_TRY((launch_sort<T, 256, 2048>(L + 2ull * rows, hc[2], rp, col, val, s)));
+  SPAM_TRY((launch_sort<T, 1024, 4096>(L + 3ull * rows, hc[3], rp, col, val, s)));
+  const uint32_t n_long = hc[NNUM - 1];
+  if (n_long) {
+    const uint32_t* hl = L + (uint64_t)(NNUM - 1) * rows;
+    SPAM_TRY(aux.alloc(16));
+    SPAM_HIP_TRY(hipMemsetAsync(aux.p, 0, 16, s));
+    DevBuf zero64;
+    SPAM_TRY(zero64.alloc((uint64_t)rows * 8));
+    SPAM_HIP_TRY(hipMemsetAsync(zero64.p, 0, (uint64_t)rows * 8, s));  // "flops" all < 2^32 for max_nnz_kernel
+    max_nnz_kernel<<<(n_long + 255) / 256, 256, 0, s>>>(hl, n_long, len.as<uint32_t>(), zero64.as<uint64_t>(), aux.as<uint32_t>());
+    SPAM_CHECK_LAUNCH();
+    uint32_t nmax = 0;
+    SPAM_HIP_TRY(hipMemcpyAsync(&nmax, aux.p, 4, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t nwg = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(n_long, 512),
+                                                              (uint32_t)((8ull << 30) / ((uint64_t)nmax * (4 + sizeof(T))))));
+    DevBuf scol, sval;
+    SPAM_TRY(scol.alloc((uint64_t)nwg * nmax * 4));
+    SPAM_TRY(sval.alloc((uint64_t)nwg * nmax * sizeof(T)));
+    sort_long_rows_kernel<T><<<nwg, 1024, 0, s>>>(hl, n_long, aux.as<uint32_t>() + 1, rp, col, val, cols,
+                                                  scol.as<uint32_t>(), sval.as<T>(), nmax);
+    SPAM_CHECK_LAUNCH();
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+  }
+  return SPAM_OK;
+}
+
 static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan** plan_out, uint64_t* nnz_out) {
   SPAM_TRY(check_pair(a, b));
   hipStream_t s = stream();
@@ -1711,11 +1842,26 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     SPAM_TRY(p->heavy_rows.alloc((uint64_t)p->n_heavy * 4));
     SPAM_HIP_TRY(hipMemcpyAsync(p->heavy_rows.p, L + (uint64_t)(NSYM - 1) * rows, (uint64_t)p->n_heavy * 4,
                                 hipMemcpyDeviceToDevice, s));
-    p->use_bpos = b->is_sorted && p->nchunks > 1;
+    p->b_col = b->col_idx;
+    p->b_val = b->vals;
+    if (!b->is_sorted && p->nchunks > 1) {
+      // the B pre-split needs sorted rows: sort a private copy once (the reference accepts either, flag B1)
+      SPAM_TRY(p->bs_col.alloc(b->nnz * 4));
+      SPAM_TRY(p->bs_val.alloc(b->nnz * dtype_size(b->dtype)));
+      SPAM_HIP_TRY(hipMemcpyAsync(p->bs_col.p, b->col_idx, b->nnz * 4, hipMemcpyDeviceToDevice, s));
+      SPAM_HIP_TRY(hipMemcpyAsync(p->bs_val.p, b->vals, b->nnz * dtype_size(b->dtype), hipMemcpyDeviceToDevice, s));
+      if (b->dtype == SPAM_F64)
+        SPAM_TRY(sort_rows_typed<double>(b->rows, b->cols, b->row_ptr, p->bs_col.as<uint32_t>(), p->bs_val.as<double>(), s));
+      else
+        SPAM_TRY(sort_rows_typed<float>(b->rows, b->cols, b->row_ptr, p->bs_col.as<uint32_t>(), p->bs_val.as<float>(), s));
+      p->b_col = p->bs_col.as<uint32_t>();
+      p->b_val = p->bs_val.p;
+    }
+    p->use_bpos = p->nchunks > 1;
     if (p->use_bpos) {
       SPAM_TRY(p->bpos.alloc((uint64_t)(p->nchunks + 1) * b->rows * 4));
       unsigned grid = (unsigned)std::min<uint64_t>((b->rows + 3) / 4, 16384);
-      bpos_kernel<<<grid, 256, 0, s>>>(b->row_ptr, b->col_idx, (uint32_t)b->rows, p->nchunks, p->cw_shift, p->bpos.as<uint32_t>());
+      bpos_kernel<<<grid, 256, 0, s>>>(b->row_ptr, p->b_col, (uint32_t)b->rows, p->nchunks, p->cw_shift, p->bpos.as<uint32_t>());
       SPAM_CHECK_LAUNCH();
     }
     SPAM_TRY(p->hcnt.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
@@ -1726,12 +1872,12 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     SPAM_TRY(otmp.alloc(64 * 4));
     SPAM_TRY(order_by_cost(p->heavy_rows.as<uint32_t>(), p->n_heavy, fl, otmp.as<uint32_t>(), sym_order.as<uint32_t>(), s));
     if (p->use_bpos)
-      sym_heavy_kernel<true><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, p->bpos.as<uint32_t>(),
+      sym_heavy_kernel<true><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, p->b_col, p->bpos.as<uint32_t>(),
                                                    (uint32_t)b->rows, sym_order.as<uint32_t>(), p->n_heavy,
                                                    p->hrow_of_row.as<uint32_t>(), p->nchunks, p->cw_shift,
                                                    p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
     else
-      sym_heavy_kernel<false><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, nullptr,
+      sym_heavy_kernel<false><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, p->b_col, nullptr,
                                                     (uint32_t)b->rows, sym_order.as<uint32_t>(), p->n_heavy,
                                                     p->hrow_of_row.as<uint32_t>(), p->nchunks, p->cw_shift,
                                                     p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
@@ -1819,7 +1965,7 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     l_normal = ordered.as<uint32_t>();
 #define SPAM_NUM_HEAVY_G(BPOS_, SORT_, TPB_, CWS_, LIST_, N_, PARTS_, Q_)                                          \
   num_heavy_kernel<T, BPOS_, SORT_, TPB_, CWS_><<<std::min<uint32_t>((N_) * (PARTS_), HEAVY_GRID), TPB_, 0, s>>>( \
-      a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, b->col_idx, (const T*)b->vals,                      \
+      a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, p->b_col, (const T*)p->b_val,                       \
       BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, LIST_, N_, PARTS_, Q_,                         \
       p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn, crp, cc, cv, \
       gst.as<unsigned long long>(), dbg_heavy)
@@ -1879,7 +2025,7 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     SPAM_TRY(scol.alloc((uint64_t)nwg * nmax * 4));
     SPAM_TRY(sval.alloc((uint64_t)nwg * nmax * sizeof(T)));
     const unsigned g1 = std::min<uint32_t>(n_hnum, HEAVY_GRID);
-    if (p->use_bpos)
+    if (p->use_bpos && b->is_sorted)  // stream positions follow B's OWN storage order
       minpos_heavy_kernel<true><<<g1, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, b->col_idx, p->bpos.as<uint32_t>(),
                                                     (uint32_t)b->rows, p->cw_shift, hl, n_hnum, d_aux + 1,
                                                     p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hoff.as<uint32_t>(), crp,
@@ -1987,6 +2133,25 @@ int spam_spgemm_numeric_f32(spam_spgemm_plan* plan, int sort_rows, uint64_t* off
   int e = spam_csr_download_f32(c, offsets_out, indices_out, vals_out);
   spam_csr_free(c);
   return e;
+}
+
+int spam_csr_sort_rows(spam_csr* m) {
+  clear_error();
+  if (!m) return set_error(SPAM_E_INVALID, "matrix is NULL");
+  if (m->is_sorted) return SPAM_OK;
+  if (!m->owns_col_val) return set_error(SPAM_E_INVALID, "cannot sort a borrowed matrix in place (views, spam_csr_from_device)");
+  hipStream_t s = stream();
+  if (m->dtype == SPAM_F64)
+    SPAM_TRY(sort_rows_typed<double>(m->rows, m->cols, m->row_ptr, m->col_idx, (double*)m->vals, s));
+  else
+    SPAM_TRY(sort_rows_typed<float>(m->rows, m->cols, m->row_ptr, m->col_idx, (float*)m->vals, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  m->is_sorted = 1;
+  if (m->spmv_plan) {  // the hot-column remap mirrors col_idx
+    spmv_plan_free(m->spmv_plan);
+    m->spmv_plan = nullptr;
+  }
+  return SPAM_OK;
 }
 
 int spam_spgemm_plan_stats(const spam_spgemm_plan* plan, spam_spgemm_stats* stats) {
