@@ -4,7 +4,7 @@ over xGMI; "gloo" for CPU tests and single-GPU rehearsals).
 The reference is single-process; its only partition is rows_to_threads (spam_csr/src/mul_hash.rs:38-64),
 contiguous row ranges balanced by intermediate products.  The same rule cuts A across GPUs (tnum = world
 size).  C's rows depend on the matching rows of A and ALL of B, so the one exchange step is an all-gather
-of B's CSR arrays (row blocks are unequal, so it is an all-gather-v built from per-source broadcasts);
+of B's CSR arrays (row blocks are unequal: shards are padded to the longest and moved by one all-gather per array);
 nothing is reduced and C stays row-sharded.  Everything here works on torch tensors of any device, so the
 logic is exercised on CPU with gloo (tests/test_dist_cpu.py).
 """
@@ -43,18 +43,42 @@ def allgather_csr(row_ptr: torch.Tensor, col_idx: torch.Tensor, vals: torch.Tens
     rp = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
     lo, hi = equal_row_block(n_rows, rank, world)
     s0 = starts_h[rank]
-    col[s0:s0 + nnz_local] = col_idx
-    val[s0:s0 + nnz_local] = vals
-    rp[lo:hi] = row_ptr[:-1] + s0  # row_ptr fix-up by the source rank's global nnz offset
     rp[n_rows] = nnz_tot
-    for r in range(world):  # unequal shards: one broadcast per source and array
-        r0, r1 = equal_row_block(n_rows, r, world)
-        a0, a1 = starts_h[r], starts_h[r] + sizes_h[r]
-        if a1 > a0:
-            dist.broadcast(col[a0:a1], src=r)
-            dist.broadcast(val[a0:a1], src=r)
-        if r1 > r0:
-            dist.broadcast(rp[r0:r1], src=r)
+    try:
+        # one padded all-gather per array (3 collectives: on xGMI every peer link carries one shard concurrently),
+        # then each shard is copied to its place; falls back to per-source broadcasts where the backend lacks it
+        maxn = max(sizes_h)
+        maxr = max(equal_row_block(n_rows, r, world)[1] - equal_row_block(n_rows, r, world)[0] for r in range(world))
+        pc = torch.zeros(maxn, dtype=col_idx.dtype, device=dev)
+        pv = torch.zeros(maxn, dtype=vals.dtype, device=dev)
+        pr = torch.zeros(maxr, dtype=torch.int64, device=dev)
+        pc[:nnz_local] = col_idx
+        pv[:nnz_local] = vals
+        pr[:hi - lo] = row_ptr[:-1] + s0  # row_ptr fix-up by the source rank's global nnz offset
+        gc = torch.empty(world * maxn, dtype=col_idx.dtype, device=dev)
+        gv = torch.empty(world * maxn, dtype=vals.dtype, device=dev)
+        gr = torch.empty(world * maxr, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gc, pc)
+        dist.all_gather_into_tensor(gv, pv)
+        dist.all_gather_into_tensor(gr, pr)
+        for r in range(world):
+            r0, r1 = equal_row_block(n_rows, r, world)
+            a0, a1 = starts_h[r], starts_h[r] + sizes_h[r]
+            col[a0:a1] = gc[r * maxn:r * maxn + sizes_h[r]]
+            val[a0:a1] = gv[r * maxn:r * maxn + sizes_h[r]]
+            rp[r0:r1] = gr[r * maxr:r * maxr + (r1 - r0)]
+    except (RuntimeError, NotImplementedError):
+        col[s0:s0 + nnz_local] = col_idx
+        val[s0:s0 + nnz_local] = vals
+        rp[lo:hi] = row_ptr[:-1] + s0
+        for r in range(world):  # unequal shards: one broadcast per source and array
+            r0, r1 = equal_row_block(n_rows, r, world)
+            a0, a1 = starts_h[r], starts_h[r] + sizes_h[r]
+            if a1 > a0:
+                dist.broadcast(col[a0:a1], src=r)
+                dist.broadcast(val[a0:a1], src=r)
+            if r1 > r0:
+                dist.broadcast(rp[r0:r1], src=r)
     return rp, col, val
 
 
