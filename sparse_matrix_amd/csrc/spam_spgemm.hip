@@ -134,6 +134,18 @@ __global__ __launch_bounds__(256) void bin_rows_kernel(const KeyT* __restrict__ 
   }
 }
 
+// LDS float add.  ds_add_f64 runs at ~2.7 lane-ops/clk/CU, but ds_add_f32 only at 0.38 on gfx950 while a CAS loop on
+// the bit pattern reaches 2.4 (tools/lds_atomic_bench.hip, profiles/r01_lds_atomic_microbench.txt) — so f32 uses the loop.
+__device__ __forceinline__ void lds_add(double* p, double v) { atomicAdd(p, v); }
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  uint32_t* q = (uint32_t*)p;
+  uint32_t old = *q, assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(q, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+  } while (old != assumed);
+}
+
 // ---- linprobe in LDS --------------------------------------------------------------------------------
 // linprobe::HashSet::insert (set.rs:128-160) with the claim made atomic: returns true when the key is new.
 __device__ __forceinline__ bool lds_set_insert(uint32_t* table, uint32_t mask, uint32_t key) {
@@ -155,7 +167,7 @@ __device__ __forceinline__ void lds_map_upsert(uint32_t* keys, T* vals, uint32_t
   for (;;) {
     const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, key);
     if (old == EMPTY_KEY || old == key) {
-      atomicAdd(&vals[h], v);
+      lds_add(&vals[h], v);
       return;
     }
     h = (h + 1) & mask;
@@ -207,13 +219,13 @@ __device__ __forceinline__ void lds_map_upsert_batch(uint32_t* keys, T* vals, ui
   for (int j = 0; j < U; ++j) {
     if (ok[j]) {
       if (old[j] == EMPTY_KEY || old[j] == k[j]) {
-        atomicAdd(&vals[h[j]], v[j]);
+        lds_add(&vals[h[j]], v[j]);
       } else {
         uint32_t hh = (h[j] + 1) & mask;
         for (;;) {
           const uint32_t o = atomicCAS(&keys[hh], EMPTY_KEY, k[j]);
           if (o == EMPTY_KEY || o == k[j]) {
-            atomicAdd(&vals[hh], v[j]);
+            lds_add(&vals[hh], v[j]);
             break;
           }
           hh = (hh + 1) & mask;
@@ -1023,7 +1035,7 @@ __global__ __launch_bounds__(TPB) void num_heavy_kernel(
             for (int j = 0; j < HEAVY_U; ++j) {
               if (okv[j]) {
                 const uint32_t c = cols[j] - c0;
-                atomicAdd(&acc[c], prods[j]);
+                lds_add(&acc[c], prods[j]);
                 flags[c] = 1;
               }
             }

@@ -28,7 +28,13 @@ __global__ __launch_bounds__(1024) void k(uint32_t* out, int iters, uint32_t nsl
       else if (MODE == 3) sink += atomicCAS(&a32[s], 0xFFFFFFFFu, h);
       else if (MODE == 4) acc[s] = (double)h;
       else if (MODE == 5) sink += atomicAdd(&a32[s], 1u);
-      else { double v = acc[s]; acc[s] = v + 1.0; }
+      else if (MODE == 6) { double v = acc[s]; acc[s] = v + 1.0; }
+      else if (MODE == 7) {  // f32 add as a CAS loop on the bit pattern
+        uint32_t old = a32[s], assumed;
+        do { assumed = old; old = atomicCAS(&a32[s], assumed, __float_as_uint(__uint_as_float(assumed) + 1.0f)); } while (old != assumed);
+      } else if (MODE == 8) {  // f32 add with the returning form
+        sink += __float_as_uint(atomicAdd(&f32[s], 1.0f));
+      } else { sink += __float_as_uint(__hip_atomic_fetch_add(&f32[s], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
     }
   }
   __syncthreads();
@@ -63,5 +69,8 @@ int main() {
   run<3, 1>("ds_cmpst_rtn_b32 (waited), lane-contiguous", 16384);
   run<4, 0>("ds_write_b64 plain, random", 16384);
   run<6, 0>("ds_read_b64+add+ds_write_b64 (non-atomic), random", 16384);
+  run<7, 0>("f32 add via CAS loop, random", 16384);
+  run<8, 0>("ds_add_rtn_f32 (waited), random", 16384);
+  run<9, 0>("__hip_atomic_fetch_add f32 workgroup scope", 16384);
   return 0;
 }
