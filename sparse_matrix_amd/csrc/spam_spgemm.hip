@@ -329,27 +329,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /
   return off + inc - v;
 }
 
-__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wsum /* [17] */) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  __syncthreads();  // wsum may still be read from the previous call
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  uint32_t off = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const uint32_t c = wsum[i];
-    if (i < w) off += c;
-    tot += c;
-  }
-  if (threadIdx.x == 0) wsum[16] = tot;
-  return off + inc - v;
-}
 
 // largest s in [0, n) with seg_start[s] <= idx   (seg_start is non-decreasing, seg_start[0] = 0)
 __device__ __forceinline__ uint32_t seg_find(const uint32_t* seg_start, uint32_t n, uint32_t idx) {

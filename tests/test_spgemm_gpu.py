@@ -360,3 +360,17 @@ def test_sort_rows_in_place(spam, oracle):
     assert d.dims()[4] is True and d.invariants()
     go, gi, gv = d.download()
     assert np.array_equal(go, off) and np.array_equal(gi, idx) and np.array_equal(gv, val)
+
+
+def test_column_range_limit(spam):
+    """Column keys must stay below u32::MAX (mul_hash.rs:12, linprobe/src/set.rs:110): cols = 2^32 - 1 is refused at
+    upload (SPAM_E_INDEX_RANGE); cols = 2^32 - 2 with an entry in the last column is accepted."""
+    off = np.array([0, 1], dtype=np.uint64)
+    val = np.array([1.0])
+    with pytest.raises(spam.SpamError) as e:
+        spam.CsrMatrix(1, 2 ** 32 - 1, val, np.array([5], dtype=np.uint64), off, True).device()
+    assert e.value.code == 2
+    ok = spam.CsrMatrix(1, 2 ** 32 - 2, val, np.array([2 ** 32 - 3], dtype=np.uint64), off, True)
+    assert ok.device().invariants()
+    with pytest.raises(spam.SpamError):          # index >= cols (invariant 5)
+        spam.CsrMatrix(1, 10, val, np.array([10], dtype=np.uint64), off, True).device()
