@@ -35,7 +35,7 @@ namespace spam {
 // ---- geometry -------------------------------------------------------------------------------------
 // numeric chunk width of the heavy path: 2^14 columns with 1024-thread workgroups (157 KB of LDS, one per CU).  The
 // 2^13 / 512-thread geometry (80 KB, two per CU) exists for A/B runs (SPAM_HEAVY_TPB=512): it doubles the number of
-// chunk groups and measured 1.65x slower on R-MAT scale 20.
+// chunk groups and measured 10 % slower on R-MAT scale 20 (225 vs 203 ms numeric).
 constexpr int CW_SHIFT_SMALL = 13, CW_SHIFT_LARGE = 14;
 constexpr uint32_t MAXCH_SMALL = 512, MAXCH_LARGE = 1024;  // chunks per row the LDS group list can hold
 
@@ -829,7 +829,7 @@ constexpr uint32_t GIANT_NNZ_A = 1024;  // A rows longer than this are cut into 
 constexpr uint32_t GIANT_PARTS = 16;
 
 template <class T, bool USE_BPOS, bool SORT, int TPB, int CWS>
-__global__ __launch_bounds__(TPB) void num_heavy_kernel(
+__global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD: two 512-thread workgroups can share a CU
     const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
     const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col, const T* __restrict__ b_val,
     const uint32_t* __restrict__ bpos, uint32_t rows_b, const uint32_t* __restrict__ rows_list, uint32_t n_rows,
@@ -1823,7 +1823,7 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     const char* cfg = getenv("SPAM_HEAVY_TPB");  // 512 / 1024: force a heavy-path geometry (A/B runs)
     const uint64_t nch_small = (b->cols + (1u << CW_SHIFT_SMALL) - 1) >> CW_SHIFT_SMALL;
     const bool small_ok = nch_small <= MAXCH_SMALL;
-    p->cw_shift = (small_ok && cfg && atoi(cfg) == 512) ? CW_SHIFT_SMALL : CW_SHIFT_LARGE;  // 512 measured slower (more, smaller groups)
+    p->cw_shift = (small_ok && cfg && atoi(cfg) == 512) ? CW_SHIFT_SMALL : CW_SHIFT_LARGE;  // 512: 10 % slower
     p->nchunks = (uint32_t)((b->cols + (1ull << p->cw_shift) - 1) >> p->cw_shift);
   }
   if (p->n_heavy) {
@@ -1960,6 +1960,12 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
       BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, LIST_, N_, PARTS_, Q_,                         \
       p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn, crp, cc, cv, \
       gst.as<unsigned long long>(), dbg_heavy)
+    if (dbg_heavy & 64) {  // residency of the two heavy geometries on this device
+      int o512 = 0, o1024 = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o512, num_heavy_kernel<T, true, false, 512, CW_SHIFT_SMALL>, 512, 0);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1024, num_heavy_kernel<T, true, false, 1024, CW_SHIFT_LARGE>, 1024, 0);
+      fprintf(stderr, "[spam dbg] workgroups per CU: 512-thread geometry %d, 1024-thread geometry %d\n", o512, o1024);
+    }
 #define SPAM_NUM_HEAVY(BPOS_, SORT_, LIST_, N_, PARTS_, Q_)                                       \
   do {                                                                                            \
     if (p->cw_shift == CW_SHIFT_SMALL)                                                            \
