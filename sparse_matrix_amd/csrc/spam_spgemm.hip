@@ -400,7 +400,7 @@ __global__ __launch_bounds__(TPB) void sym_row_kernel(const uint64_t* __restrict
       uint32_t total;
       const uint32_t st = block_excl_scan_tot<TPB>(len, wsum, total);
       seg_start[threadIdx.x] = st;
-      seg_lo[threadIdx.x] = lo;
+      seg_lo[threadIdx.x] = lo - st;  // q = seg_lo[s] + idx for a product index idx of segment s
       if (threadIdx.x == 0) seg_start[SEG] = total;
       __syncthreads();
       const uint32_t upl = total >= TPB * ROW_U ? ROW_U : (total + TPB - 1) / TPB;  // spread small rows over all waves
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(TPB) void sym_row_kernel(const uint64_t* __restrict
           cols[j] = EMPTY_KEY;
           if (j < upl && idx < total) {
             sg = seg_advance(seg_start, SEG, sg, idx);
-            cols[j] = b_col[seg_lo[sg] + (idx - seg_start[sg])];
+            cols[j] = b_col[seg_lo[sg] + idx];
           }
         }
         mine += lds_set_insert_batch<ROW_U>(table, mask, cols);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(TPB) void num_row_kernel(
       uint32_t total;
       const uint32_t st = block_excl_scan_tot<TPB>(len, wsum, total);
       seg_start[threadIdx.x] = st;
-      seg_lo[threadIdx.x] = lo;
+      seg_lo[threadIdx.x] = lo - st;  // q = seg_lo[s] + idx for a product index idx of segment s
       if (threadIdx.x == 0) seg_start[SEG] = total;
       __syncthreads();
       const uint32_t upl = total >= TPB * ROW_U ? ROW_U : (total + TPB - 1) / TPB;  // spread small rows over all waves
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(TPB) void num_row_kernel(
           prods[j] = T(0);
           if (j < upl && idx < total) {
             sg = seg_advance(seg_start, SEG, sg, idx);
-            const uint32_t q = seg_lo[sg] + (idx - seg_start[sg]);
+            const uint32_t q = seg_lo[sg] + idx;
             cols[j] = b_col[q];
             prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
           }
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
         uint32_t total;
         const uint32_t st = block_excl_scan_tot<1024>(len, wsum, total);
         seg_start[threadIdx.x] = st;
-        seg_lo[threadIdx.x] = lo;
+        seg_lo[threadIdx.x] = lo - st;  // q = seg_lo[s] + idx for a product index idx of segment s
         if (threadIdx.x == 0) seg_start[SEG] = total;
         __syncthreads();
         // each wavefront takes 64*HEAVY_U consecutive products per round, lane-contiguous inside every load
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
             cols[j] = 0xFFFFFFFFu;
             if (idx < total) {
               sg = seg_advance(seg_start, SEG, sg, idx);
-              cols[j] = b_col[seg_lo[sg] + (idx - seg_start[sg])];
+              cols[j] = b_col[seg_lo[sg] + idx];
             }
           }
 #pragma unroll
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
         const uint32_t st = block_excl_scan_tot<TPB>(len, wsum, total);
         if (threadIdx.x < SEG) {
           seg_start[threadIdx.x] = st;
-          seg_lo[threadIdx.x] = lo;
+          seg_lo[threadIdx.x] = lo - st;  // q = seg_lo[s] + idx for a product index idx of segment s
         }
         if (threadIdx.x == 0) seg_start[SEG] = total;
         __syncthreads();
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
             prods[j] = T(0);
             if (j < upl && idx < total) {
               sg = seg_advance(seg_start, SEG, sg, idx);
-              const uint32_t q = seg_lo[sg] + (idx - seg_start[sg]);
+              const uint32_t q = seg_lo[sg] + idx;
               cols[j] = b_col[q];
               prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
             }
@@ -1221,12 +1221,12 @@ __global__ __launch_bounds__(1024) void ref_order_kernel(const uint64_t* __restr
       uint32_t total;
       const uint32_t st = block_excl_scan_tot<TPB>(len, wsum, total);
       seg_start[threadIdx.x] = st;
-      seg_lo[threadIdx.x] = lo;
+      seg_lo[threadIdx.x] = lo - st;  // q = seg_lo[s] + idx for a product index idx of segment s
       if (threadIdx.x == 0) seg_start[SEG] = total;
       __syncthreads();
       for (uint32_t idx = threadIdx.x; idx < total; idx += TPB) {
         const uint32_t sg = seg_find(seg_start, SEG, idx);
-        const uint32_t key = b_col[seg_lo[sg] + (idx - seg_start[sg])];
+        const uint32_t key = b_col[seg_lo[sg] + idx];
         uint32_t h = (key * HASH_SCAL) & mask;
         for (;;) {
           const uint32_t old = atomicCAS(&k1[h], EMPTY_KEY, key);
@@ -1345,7 +1345,7 @@ __global__ __launch_bounds__(1024) void minpos_heavy_kernel(
         const uint32_t batch_full = wsum[TPB / 64];
         const uint32_t st = block_excl_scan<TPB>(len, wsum);
         seg_start[threadIdx.x] = st;
-        seg_lo[threadIdx.x] = lo;
+        seg_lo[threadIdx.x] = lo - st;  // q = seg_lo[s] + idx for a product index idx of segment s
         seg_pos[threadIdx.x] = carry + before + skip;
         __syncthreads();
         const uint32_t total = wsum[TPB / 64];
@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(1024) void minpos_heavy_kernel(
         for (uint32_t idx = threadIdx.x; idx < total; idx += TPB) {
           const uint32_t sg = seg_find(seg_start, SEG, idx);
           const uint32_t off = idx - seg_start[sg];
-          const uint32_t c = b_col[seg_lo[sg] + off] - c0;
+          const uint32_t c = b_col[seg_lo[sg] + idx] - c0;
           if (c < MP_COLS && c < ((j1 - j0) << cw_shift)) atomicMin(&mp[c], seg_pos[sg] + off);
         }
         carry += batch_full;
