@@ -113,6 +113,12 @@ int spam_csr_sort_rows(spam_csr* m);
 int spam_csr_invariants(const spam_csr* m, int* ok);
 void spam_csr_free(spam_csr* m);
 
+/* C = A + B (subtract = 0) or A - B (subtract = 1): `impl Add / Sub for CsrMatrix` through apply_elementwise
+ * (spam_csr/src/lib.rs:83-149, 276-290).  Rows of C are the sorted union of the rows of A and B; entries whose
+ * result is zero are kept, as in the reference.  Unsorted operands are sorted in private copies first (the
+ * reference's HashMap path leaves their order unspecified).  Dimensions must match (assert_eq!, lib.rs:87-91). */
+int spam_csr_add(const spam_csr* a, const spam_csr* b, int subtract, spam_csr** out);
+
 /* ---- SpMV: y = A x --------------------------------------------------------------------------
  * Absent from the reference; defined as mul_hash with an n x 1 right-hand side (SURVEY.md §3.5,
  * mul_hash.rs:145-163): rows without entries give 0.  x has cols(A) entries, y rows(A). */

@@ -154,6 +154,25 @@ def mul_hash(a, b, sort_rows: bool = False, tnum: int | None = None):
     return offsets, indices, vals
 
 
+def apply_elementwise(a, b, subtract: bool = False, is_sorted: bool = True):
+    """impl Add / Sub for CsrMatrix (spam_csr/src/lib.rs:83-149, 276-290).  Returns (offsets, indices, vals)."""
+    a_off, a_idx, a_val = _u64(a[0]), _u64(a[1]), np.ascontiguousarray(a[2])
+    b_off, b_idx, b_val = _u64(b[0]), _u64(b[1]), np.ascontiguousarray(b[2])
+    if a_off.size != b_off.size:
+        raise OracleError(ORC_E_ASSERT)  # assert_eq!((rows, cols), ...) (lib.rs:87-91)
+    sfx = _DT[a_val.dtype]
+    rows = a_off.size - 1
+    cap = a_idx.size + b_idx.size
+    offsets = np.empty(rows + 1, dtype=np.uint64)
+    indices = np.empty(cap, dtype=np.uint64)
+    vals = np.empty(cap, dtype=a_val.dtype)
+    fn = getattr(lib(), f"orc_apply_elementwise_{sfx}")
+    fn.restype = C.c_uint64
+    n = fn(C.c_uint64(rows), _p(a_off), _p(a_idx), _p(a_val), _p(b_off), _p(b_idx), _p(b_val), C.c_int(int(subtract)),
+           C.c_int(int(is_sorted)), _p(offsets), _p(indices), _p(vals))
+    return offsets, indices[:n].copy(), vals[:n].copy()
+
+
 def spmv(a, x, nthreads: int = 1) -> np.ndarray:
     """y = A x with the summation order mul_hash gives for an n x 1 right-hand side."""
     a_off, a_idx, a_val = _u64(a[0]), _u64(a[1]), np.ascontiguousarray(a[2])

@@ -350,6 +350,50 @@ void spmv(CsrView a, const T* a_vals, const T* x, T* y, unsigned nthreads) {
   for (auto& x_ : th) x_.join();
 }
 
+// spam_csr/src/lib.rs:83-149 apply_elementwise (behind impl Add / Sub, :276-290).
+// IS_SORTED: merge_join_by column (:101-118): Both -> f(t1, t2), Left -> f(t, 0), Right -> f(0, t); results equal
+// to zero are kept.  Unsorted rows go through std::collections::HashMap (:119-134) whose iteration order is
+// unspecified; this restatement emits them sorted by column (compare as sets).
+template <class T>
+usize apply_elementwise(CsrView a, const T* a_vals, CsrView b, const T* b_vals, bool subtract, bool is_sorted,
+                        usize* offsets, usize* indices, T* vals) {
+  auto f = [&](T x, T y) {
+    if constexpr (std::is_integral_v<T>) {
+      using U = std::make_unsigned_t<T>;
+      return subtract ? (T)(U)((U)x - (U)y) : (T)(U)((U)x + (U)y);
+    } else {
+      return subtract ? x - y : x + y;
+    }
+  };
+  usize out = 0;
+  offsets[0] = 0;
+  std::vector<std::pair<usize, T>> ra, rb;
+  for (usize r = 0; r < a.rows; ++r) {
+    ra.clear();
+    rb.clear();
+    for (usize p = a.offsets[r]; p < a.offsets[r + 1]; ++p) ra.emplace_back(a.indices[p], a_vals[p]);
+    for (usize p = b.offsets[r]; p < b.offsets[r + 1]; ++p) rb.emplace_back(b.indices[p], b_vals[p]);
+    if (!is_sorted) {
+      auto cmp = [](auto& x, auto& y) { return x.first < y.first; };
+      std::sort(ra.begin(), ra.end(), cmp);
+      std::sort(rb.begin(), rb.end(), cmp);
+    }
+    size_t i = 0, j = 0;
+    while (i < ra.size() || j < rb.size()) {
+      if (j == rb.size() || (i < ra.size() && ra[i].first < rb[j].first)) {
+        indices[out] = ra[i].first, vals[out] = f(ra[i].second, T(0)), ++i;
+      } else if (i == ra.size() || rb[j].first < ra[i].first) {
+        indices[out] = rb[j].first, vals[out] = f(T(0), rb[j].second), ++j;
+      } else {
+        indices[out] = ra[i].first, vals[out] = f(ra[i].second, rb[j].second), ++i, ++j;
+      }
+      ++out;
+    }
+    offsets[r + 1] = out;
+  }
+  return out;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -410,6 +454,12 @@ int orc_mul_hash_symbolic(uint64_t a_rows, const uint64_t* a_off, const uint64_t
                                     int sort_rows, uint64_t* offsets, uint64_t* indices, T* vals) {                \
     return mul_hash_numeric<T>(CsrView{a_rows, a_off, a_idx}, a_val, CsrView{b_rows, b_off, b_idx}, b_val, row_nz, \
                                rows_offset, tnum, sort_rows != 0, offsets, indices, vals);                         \
+  }                                                                                                                \
+  uint64_t orc_apply_elementwise_##SUFFIX(uint64_t rows, const uint64_t* a_off, const uint64_t* a_idx, const T* a_val, \
+                                          const uint64_t* b_off, const uint64_t* b_idx, const T* b_val, int subtract, \
+                                          int is_sorted, uint64_t* offsets, uint64_t* indices, T* vals) {              \
+    return apply_elementwise<T>(CsrView{rows, a_off, a_idx}, a_val, CsrView{rows, b_off, b_idx}, b_val, subtract != 0,  \
+                                is_sorted != 0, offsets, indices, vals);                                               \
   }                                                                                                                \
   void orc_spmv_##SUFFIX(uint64_t a_rows, const uint64_t* a_off, const uint64_t* a_idx, const T* a_val,            \
                          const T* x, T* y, unsigned nthreads) {                                                    \

@@ -67,6 +67,7 @@ SYMBOLS = {
     "spam_csr_download_f32": (C.c_int, [_P, _P, _P, _P]),
     "spam_csr_sort_rows": (C.c_int, [_P]),
     "spam_csr_invariants": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "spam_csr_add": (C.c_int, [_P, _P, C.c_int, _PP]),
     "spam_csr_free": (None, [_P]),
     "spam_spmv_f64": (C.c_int, [_P, _P, _P]),
     "spam_spmv_f32": (C.c_int, [_P, _P, _P]),

@@ -3,8 +3,8 @@
 Same names, argument meaning and error behaviour as the Rust type (spam_csr/src/lib.rs:25-32,151-197,
 292-358) and the ``Matrix`` trait (spam_matrix/src/lib.rs:15-27) for everything on the SpMV / SpGEMM path;
 ``mul_hash`` (spam_csr/src/mul_hash.rs:13-36) and the new ``spmv`` run on the GPU through the C ABI in
-include/spam_hip.h.  Element-wise get/set/transpose/add/sub are off the hot path and stay with the
-reference's CPU code — they are not provided here.
+include/spam_hip.h.  ``+`` / ``-`` (apply_elementwise, lib.rs:83-149) also run on the device; element get/set and transpose stay with the
+reference's CPU code and are not provided here.
 """
 from __future__ import annotations
 
@@ -98,6 +98,12 @@ class DeviceCsr:
         a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(_lib.load().spam_csr_device_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def add(self, rhs: "DeviceCsr", subtract: bool = False) -> "DeviceCsr":
+        """C = self + rhs / self - rhs on the device (sorted union rows, zeros kept)."""
+        h = C.c_void_p()
+        check(_lib.load().spam_csr_add(self._h, rhs._h, int(bool(subtract)), C.byref(h)))
+        return DeviceCsr(h)
 
     def sort_rows(self):
         """In-place per-row sort by column (the handle becomes IS_SORTED = true)."""
@@ -289,6 +295,19 @@ class CsrMatrix:
         finally:
             L.spam_spgemm_plan_free(plan)
         return CsrMatrix(self._rows, rhs._cols, vals, indices, offsets, is_sorted=sort_output)
+
+    def _ewise(self, rhs: "CsrMatrix", subtract: bool) -> "CsrMatrix":
+        d = self.device().add(rhs.device(), subtract)
+        o, i, v = d.download()
+        return CsrMatrix(self._rows, self._cols, v, i, o, is_sorted=True)
+
+    def __add__(self, rhs):
+        """``impl Add for CsrMatrix`` (spam_csr/src/lib.rs:276-282)."""
+        return self._ewise(rhs, False)
+
+    def __sub__(self, rhs):
+        """``impl Sub for CsrMatrix`` (spam_csr/src/lib.rs:284-290)."""
+        return self._ewise(rhs, True)
 
     def __mul__(self, rhs):
         """``impl Mul for &CsrMatrix`` -> ``CsrMatrix<T, false>`` (spam_csr/src/lib.rs:292-297)."""

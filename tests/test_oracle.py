@@ -218,3 +218,32 @@ def test_spmv_is_mul_hash_with_one_column(oracle):
             dense[r] = v[off[r]]
     assert np.array_equal(dense, y)
     assert np.array_equal(oracle.spmv(a, x, nthreads=4), y)
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.integers(1, 5), st.integers(1, 5), st.data())
+def test_add_sub_equal_dok_elementwise_wrapping_i8(rows, cols, data):
+    """The reference's add test shape (spam_csr/src/tests.rs:334-354): CSR +/- CSR, converted to DOK (zeros dropped),
+    equals the dense wrapping-i8 sum; the sorted result keeps structural zeros and satisfies the invariants."""
+    import oracle
+
+    def mat():
+        ents = data.draw(st.dictionaries(st.tuples(st.integers(0, rows - 1), st.integers(0, cols - 1)),
+                                         st.integers(-128, 127).filter(lambda v: v != 0), max_size=2 * rows * cols))
+        items = sorted(ents.items())
+        counts = np.zeros(rows, dtype=np.uint64)
+        for (i, _), _ in items:
+            counts[i] += 1
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        return (off, np.array([j for (_, j), _ in items], dtype=np.uint64), np.array([v for _, v in items], dtype=np.int8))
+
+    a, b = mat(), mat()
+    for sub in (False, True):
+        o, i, v = oracle.apply_elementwise(a, b, subtract=sub, is_sorted=True)
+        assert dok.invariants(rows, cols, o, i, v, is_sorted=True)
+        ad, bd = dok.to_dense(rows, cols, *a), dok.to_dense(rows, cols, *b)
+        with np.errstate(over="ignore"):
+            want = (ad - bd) if sub else (ad + bd)
+        assert dok.to_map(rows, o, i, v) == dok.dense_to_map(want)
+        assert len(i) == len(set(zip(np.repeat(np.arange(rows), np.diff(a[0].astype(np.int64))), a[1])) |
+                             set(zip(np.repeat(np.arange(rows), np.diff(b[0].astype(np.int64))), b[1])))
