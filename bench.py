@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--spgemm-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv", action="store_true")
+    ap.add_argument("--spmv-sharded", action="store_true",
+                    help="N > 1: ONE 10 M-row matrix row-sharded over the ranks, x all-gathered every step (strong scaling) "
+                         "instead of one matrix per rank (weak scaling, the default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,39 +107,61 @@ def main():
     # ------------------------------------------------------------------ SpMV (primary) -------------
     if not args.no_spmv:
         t0 = time.time()
-        A = synth.rmat_rect(args.spmv_rows, args.spmv_nnz, seed=42 + rank, dtype=torch.float64, device=dev,
-                            oversample=args.spmv_oversample)
-        x = synth.dense_vector(A.cols, dtype=torch.float64, device=dev)
+        sharded = args.spmv_sharded and world > 1
+        if sharded:
+            # ONE matrix, rank r holds rows [r*n/world, (r+1)*n/world) and the matching slice of x
+            rlo, rhi = spdist.equal_row_block(args.spmv_rows, rank, world)
+            A = synth.rmat_rect(args.spmv_rows, args.spmv_nnz, seed=42, dtype=torch.float64, device=dev,
+                                oversample=args.spmv_oversample, row_range=(rlo, rhi))
+            x_local = synth.dense_vector(args.spmv_rows, dtype=torch.float64, device=dev)[rlo:rhi].clone()
+            x = spdist.allgather_vector(x_local, args.spmv_rows, rank, world, dist)
+        else:
+            A = synth.rmat_rect(args.spmv_rows, args.spmv_nnz, seed=42 + rank, dtype=torch.float64, device=dev,
+                                oversample=args.spmv_oversample)
+            x = synth.dense_vector(A.cols, dtype=torch.float64, device=dev)
         y = torch.empty(A.rows, dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
         stA = A.stats()
         log(f"[spmv] generated {stA} in {time.time() - t0:.1f}s")
         dA = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, A.vals, True)
         nbytes = spmv_alg_bytes(A.rows, A.cols, A.nnz, 8)
+        if sharded:  # whole-job bytes = sum of the blocks; x is counted once per rank (every rank reads all of it)
+            tb = torch.tensor([float(nbytes)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tb)
+            job_bytes = float(tb.item())
+        def spmv_step():
+            if sharded:  # the exchange step of a row-sharded SpMV: all-gather x, inside the timed region
+                xg = spdist.allgather_vector(x_local, args.spmv_rows, rank, world, dist)
+                dA.spmv_dev(xg.data_ptr(), y.data_ptr())
+            else:
+                dA.spmv_dev(x.data_ptr(), y.data_ptr())
+
         for _ in range(args.warmup):
-            dA.spmv_dev(x.data_ptr(), y.data_ptr())
+            spmv_step()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         barrier()
         t0 = time.perf_counter()
         for s, e in evs:
             s.record()
-            dA.spmv_dev(x.data_ptr(), y.data_ptr())
+            spmv_step()
             e.record()
         barrier()
         wall = time.perf_counter() - t0
         wall = max_over_ranks(wall)
         kern_ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
         ms_per_step = wall * 1e3 / args.steps
-        value = world * nbytes / (wall / args.steps) / 1e9
+        value = (job_bytes if sharded else world * nbytes) / (wall / args.steps) / 1e9
         achieved = nbytes / (kern_ms * 1e-3) / 1e9
         out.update({
             "metric": "spmv_effective_GB_per_s", "value": round(value, 1), "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
             "config": {"workload": "csr_spmv_f64_rmat_10Mx10M_160Mnnz (BASELINE configs[1])", "rows": A.rows,
                        "cols": A.cols, "nnz": A.nnz, "avg_nnz_row": round(stA["avg_nnz_row"], 2),
                        "max_nnz_row": stA["max_nnz_row"], "gflops": round(2 * A.nnz * world / (wall / args.steps) / 1e9, 1),
-                       "sharding": "row blocks, x replicated, no collective" if world > 1 else "single GPU"},
+                       "sharding": ("one matrix row-sharded, x all-gathered every step" if sharded else
+                                    "one matrix per rank, x replicated, no collective") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "kernel": "spmv_tile_kernel(+fixup)", "kernel_ms": round(kern_ms, 4),

@@ -108,3 +108,20 @@ def balanced_row_blocks(row_flops, nparts: int, row_overhead: int = ROW_OVERHEAD
     blocks of few heavy rows with the same F (SURVEY.md §8e "cost-weighted partition")."""
     f = torch.as_tensor(row_flops).to(torch.int64).cpu()
     return rows_to_parts_host(f + row_overhead * (f > 0).to(torch.int64), nparts)
+
+
+def allgather_vector(x_local: torch.Tensor, n: int, rank: int, world: int, dist=None) -> torch.Tensor:
+    """Row-sharded SpMV needs all of x: every rank owns x[equal_row_block] and receives the rest (one padded
+    all-gather; 8 B * n / world per peer link)."""
+    if world == 1 or dist is None:
+        return x_local
+    blocks = [equal_row_block(n, r, world) for r in range(world)]
+    maxb = max(hi - lo for lo, hi in blocks)
+    pad = torch.zeros(maxb, dtype=x_local.dtype, device=x_local.device)
+    pad[: x_local.numel()] = x_local
+    out = torch.empty(world * maxb, dtype=x_local.dtype, device=x_local.device)
+    dist.all_gather_into_tensor(out, pad)
+    x = torch.empty(n, dtype=x_local.dtype, device=x_local.device)
+    for r, (lo, hi) in enumerate(blocks):
+        x[lo:hi] = out[r * maxb: r * maxb + (hi - lo)]
+    return x

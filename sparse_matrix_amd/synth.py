@@ -184,7 +184,7 @@ def rmat(scale: int, edge_factor: int = 16, seed: int = 42, dtype=torch.float64,
 
 
 def rmat_rect(n: int, nnz_target: int, seed: int = 42, dtype=torch.float64, device="cpu",
-              signed=False, chunk: int = 1 << 24, oversample: float | None = None) -> Csr:
+              signed=False, chunk: int = 1 << 24, oversample: float | None = None, row_range=None) -> Csr:
     """G-rmat clipped to n x n: sample at scale ceil(log2 n), reject row/col >= n, merge duplicates.
 
     Draws ``oversample * nnz_target`` samples (default calibrated for the Graph500 parameters), so the
@@ -199,9 +199,16 @@ def rmat_rect(n: int, nnz_target: int, seed: int = 42, dtype=torch.float64, devi
         e = torch.arange(s, min(s + chunk, m), dtype=torch.int64, device=device)
         r, c = _rmat_edges(e, scale, seed)
         ok = (r < n) & (c < n)
+        if row_range is not None:  # one rank's row block of the same matrix
+            ok &= (r >= row_range[0]) & (r < row_range[1])
         parts.append(torch.unique((r[ok] << 32) | c[ok]))
     keys = torch.cat(parts)
-    return _csr_from_keys(keys, n, n, seed, dtype, signed)
+    if row_range is None:
+        return _csr_from_keys(keys, n, n, seed, dtype, signed)
+    gkeys = torch.unique(keys, sorted=True)
+    out = _csr_from_keys(gkeys - (row_range[0] << 32), row_range[1] - row_range[0], n, seed, dtype, signed)
+    out.vals = _values(gkeys, seed, dtype, signed)  # values are a function of the GLOBAL coordinate
+    return out
 
 
 def _perm_bits(x: torch.Tensor, bits: int, k1: torch.Tensor, k2: torch.Tensor) -> torch.Tensor:

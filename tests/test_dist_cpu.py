@@ -48,6 +48,13 @@ def _worker(rank, world, port, ret):
         wo, wi, wv = oracle.mul_hash(a, a, sort_rows=True, tnum=1)
         s, e = int(wo[mylo]), int(wo[myhi])
         assert np.array_equal(o, wo[mylo:myhi + 1] - wo[mylo]) and np.array_equal(i, wi[s:e]) and np.array_equal(v, wv[s:e])
+        # row-sharded SpMV: all-gather x, multiply the local row block, compare with the matching slice of A x
+        xfull = synth.dense_vector(n)
+        xl = xfull[lo:hi].clone()
+        xg = spdist.allgather_vector(xl, n, rank, world, dist)
+        assert torch.equal(xg, xfull)
+        yb = oracle.spmv(blk.cpu_numpy(), xg.numpy())
+        assert np.array_equal(yb, oracle.spmv(a, xfull.numpy())[lo:hi])
         # C's global row_ptr from one all-gather of per-rank nnz counts
         cnt = torch.zeros(world, dtype=torch.int64)
         cnt[rank] = len(i)
