@@ -167,6 +167,15 @@ def main():
                          "kernel": "spmv_tile_kernel(+fixup)", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes": nbytes},
         })
+        # what the gather allows on this chip (tools/gather_bench.hip): 245 G gathers/s when they hit L2, 52 G/s when
+        # they miss (a 128-byte line crosses the fabric per miss); the hot table makes `hot_cover` of them hit
+        info = dA.spmv_plan_info()
+        hits = info["hot_cover"] * A.nnz if info["hot_columns"] else 0.0
+        model_ms = max(nbytes / 5.8e12, hits / 245e9 + (A.nnz - hits) / 52e9) * 1e3
+        out["roofline"]["gather_model"] = {"hot_columns": info["hot_columns"], "hot_cover": round(info["hot_cover"], 4),
+                                           "l2_hit_gathers_per_s": 245e9, "l2_miss_gathers_per_s": 52e9,
+                                           "bound_ms": round(model_ms, 4), "frac_of_bound": round(model_ms / kern_ms, 4),
+                                           "source": "profiles/r01_gather_microbench.txt"}
         # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc run (tools/prof_bench.sh), never from this process
         pmc = os.path.join(ROOT, "profiles", "spmv_pmc_latest.json")
         if os.path.exists(pmc):

@@ -125,6 +125,9 @@ int spam_csr_add(const spam_csr* a, const spam_csr* b, int subtract, spam_csr** 
 int spam_spmv_f64(const spam_csr* a, const double* x_host, double* y_host); /* host slices (&[T] -> Vec<T>) */
 int spam_spmv_f32(const spam_csr* a, const float* x_host, float* y_host);
 int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y); /* device-resident vectors, asynchronous */
+/* What the SpMV analysis of this matrix decided (valid after the first SpMV on the handle): number of columns in the
+ * L2-resident hot table (0 = disabled), the share of the entries they cover, and the number of nnz tiles. */
+int spam_spmv_plan_info(const spam_csr* a, uint64_t* hot_columns, double* hot_cover, uint64_t* tiles);
 
 /* ---- SpGEMM: C = A B, two phases like mul_hash ----------------------------------------------
  * spam_spgemm_symbolic  = rows_to_threads' flop count (mul_hash.rs:39-50) + mul_hash_symbolic (:66-103)

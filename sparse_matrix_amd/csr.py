@@ -134,6 +134,11 @@ class DeviceCsr:
     def spmv_dev(self, x_ptr: int, y_ptr: int):
         check(_lib.load().spam_spmv_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
 
+    def spmv_plan_info(self) -> dict:
+        k, cov, tiles = C.c_uint64(), C.c_double(), C.c_uint64()
+        check(_lib.load().spam_spmv_plan_info(self._h, C.byref(k), C.byref(cov), C.byref(tiles)))
+        return {"hot_columns": k.value, "hot_cover": cov.value, "tiles": tiles.value}
+
     def spmv(self, x: np.ndarray) -> np.ndarray:
         rows, cols, _, dt, _ = self.dims()
         x = np.ascontiguousarray(x, dtype=_DT2NP[dt])

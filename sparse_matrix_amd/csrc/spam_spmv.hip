@@ -485,6 +485,16 @@ int spam_spmv_f64(const spam_csr* a, const double* x_host, double* y_host) {
 int spam_spmv_f32(const spam_csr* a, const float* x_host, float* y_host) {
   return spmv_host<float>(a, SPAM_F32, x_host, y_host);
 }
+int spam_spmv_plan_info(const spam_csr* a, uint64_t* hot_columns, double* hot_cover, uint64_t* tiles) {
+  clear_error();
+  if (!a) return set_error(SPAM_E_INVALID, "matrix is NULL");
+  const SpmvPlan* p = a->spmv_plan;
+  if (hot_columns) *hot_columns = p ? p->hot_k : 0;
+  if (hot_cover) *hot_cover = p ? p->hot_cover : 0.0;
+  if (tiles) *tiles = p ? p->ntiles : 0;
+  return SPAM_OK;
+}
+
 int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y) {
   clear_error();
   if (!a || !d_x || !d_y) return set_error(SPAM_E_INVALID, "NULL argument");
