@@ -104,6 +104,11 @@ class CsrMatrix {
   // impl Mul for &CsrMatrix<T, B>  ->  CsrMatrix<T, false>  (lib.rs:292-297)
   CsrMatrix<T, false> operator*(const CsrMatrix& rhs) const { return mul_hash<IS_SORTED, false>(rhs); }
 
+  // impl Add / Sub for CsrMatrix (lib.rs:276-290) through apply_elementwise (lib.rs:83-149): sorted-union rows,
+  // results equal to zero are kept
+  CsrMatrix<T, true> operator+(const CsrMatrix& rhs) const { return ewise(rhs, 0); }
+  CsrMatrix<T, true> operator-(const CsrMatrix& rhs) const { return ewise(rhs, 1); }
+
   // y = A x (absent upstream; mul_hash with an n x 1 right-hand side)
   std::vector<T> spmv(const std::vector<T>& x) const {
     if (x.size() != cols_) throw Panic(SPAM_E_INVALID, "x.len() != cols");
@@ -129,6 +134,22 @@ class CsrMatrix {
   }
 
  private:
+  CsrMatrix<T, true> ewise(const CsrMatrix& rhs, int subtract) const {
+    spam_csr* c = nullptr;
+    check(spam_csr_add(device(), rhs.device(), subtract, &c));
+    uint64_t rows = 0, cols = 0, nnz = 0;
+    check(spam_csr_dims(c, &rows, &cols, &nnz, nullptr, nullptr));
+    std::vector<uint64_t> offsets(rows + 1), indices(nnz);
+    std::vector<T> vals(nnz);
+    int st;
+    if constexpr (std::is_same<T, double>::value)
+      st = spam_csr_download_f64(c, offsets.data(), indices.data(), vals.data());
+    else
+      st = spam_csr_download_f32(c, offsets.data(), indices.data(), vals.data());
+    spam_csr_free(c);
+    check(st);
+    return CsrMatrix<T, true>(rows, cols, std::move(vals), std::move(indices), std::move(offsets));
+  }
   void release() {
     if (dev_) spam_csr_free(dev_);
     dev_ = nullptr;

@@ -33,6 +33,12 @@ int main() {
       for (uint64_t p = off[i]; p < off[i + 1]; ++p) s = (p == off[i]) ? vals[p] : s + vals[p];
       if (y[i] != s) return std::printf("spmv row %llu: %g != %g\n", (unsigned long long)i, y[i], s), 1;
     }
+    auto Z = A - A;  // every entry cancels: structure kept (explicit zeros), as apply_elementwise does
+    if (Z.indices() != A.indices() || Z.nnz() != A.nnz()) return std::puts("A - A lost structure"), 1;
+    for (double v : Z.vals())
+      if (v != 0.0) return std::puts("A - A != 0"), 1;
+    auto S = A + I;
+    if (S.nnz() != A.nnz() || !S.invariants()) return std::puts("A + I pattern wrong"), 1;
     bool threw = false;
     try {
       auto B = spam::CsrMatrix<double, true>::identity(n + 1);
