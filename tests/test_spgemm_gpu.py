@@ -374,3 +374,29 @@ def test_column_range_limit(spam):
     assert ok.device().invariants()
     with pytest.raises(spam.SpamError):          # index >= cols (invariant 5)
         spam.CsrMatrix(1, 10, val, np.array([10], dtype=np.uint64), off, True).device()
+
+
+def test_randomized_shapes_all_orders(spam, oracle):
+    """120 random products (rows 1..400, inner 1..400, cols 1..60 000, densities 0.1 %..60 %, sorted or shuffled
+    operands, f64 / f32): row_ptr exact; sorted col_idx exact; table order set-equal; reference order bit-exact."""
+    rng = np.random.default_rng(2026)
+    for case in range(120):
+        l, m = int(rng.integers(1, 401)), int(rng.integers(1, 401))
+        n = int(rng.choice([1, 7, 64, 500, 5000, 20000, 60000]))
+        da = float(rng.choice([0.001, 0.01, 0.1, 0.6]))
+        db = float(rng.choice([0.001, 0.01, 0.05, 0.3])) if n <= 5000 else float(rng.choice([0.0005, 0.003, 0.02]))
+        sa, sb = bool(rng.integers(2)), bool(rng.integers(2))
+        dt = torch.float32 if case % 5 == 4 else torch.float64
+        ma = synth.random_csr(l, m, da, seed=1000 + case, signed=False, sort_rows=sa, dtype=dt)
+        mb = synth.random_csr(m, n, db, seed=5000 + case, signed=False, sort_rows=sb, dtype=dt)
+        A, a = _mk(spam, ma, sa)
+        B, b = _mk(spam, mb, sb)
+        rtol = F64_RTOL if dt == torch.float64 else F32_RTOL
+        ws = oracle.mul_hash(a, b, sort_rows=True)
+        wu = oracle.mul_hash(a, b, sort_rows=False)
+        Cs = A.mul_hash(B, sort_output=True)
+        assert_csr_parity((Cs.offsets, Cs.indices, Cs.vals), ws, True, rtol)
+        Ct = A.mul_hash(B)
+        assert_csr_parity((Ct.offsets, Ct.indices, Ct.vals), wu, False, rtol)
+        Cr = A.mul_hash(B, reference_order=True)
+        assert np.array_equal(Cr.offsets, wu[0]) and np.array_equal(Cr.indices, wu[1]), f"case {case}"
