@@ -193,3 +193,40 @@ def test_cfg5_full_size_f32_powerlaw(spam, oracle):
     ref = oracle.spmv((off, idx, val.astype(np.float64)), x.cpu().numpy().astype(np.float64), nthreads=oracle.hardware_threads())
     yh = y.cpu().numpy().astype(np.float64)
     assert (np.abs(yh - ref) / np.abs(ref)).max() <= F32_RTOL
+
+
+def test_randomized_shapes(spam, oracle):
+    """80 random matrices: rows 1..30 000, cols 1..50 000, uniform / skewed row lengths incl. rows of tens of
+    thousands of entries and empty rows, sorted or shuffled rows, f64 / f32 — against the oracle."""
+    rng = np.random.default_rng(7)
+    for case in range(80):
+        rows, cols = int(rng.integers(1, 30_001)), int(rng.integers(1, 50_001))
+        kind = case % 4
+        if kind == 0:
+            lens = rng.integers(0, 40, rows)
+        elif kind == 1:
+            lens = (rng.pareto(1.2, rows) * 3).astype(np.int64)
+        elif kind == 2:
+            lens = np.where(rng.random(rows) < 0.002, rng.integers(5000, 40_000, rows), rng.integers(0, 6, rows))
+        else:
+            lens = np.zeros(rows, dtype=np.int64)
+            lens[rng.integers(0, rows, max(1, rows // 50))] = rng.integers(1, 3000)
+        lens = np.minimum(lens, cols)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        idx = np.concatenate([rng.choice(cols, int(k), replace=False) for k in lens if k] or [np.empty(0, dtype=np.int64)])
+        is_sorted = bool(case % 3)
+        if is_sorted and idx.size:
+            o = off.astype(np.int64)
+            row_of = np.repeat(np.arange(rows), np.diff(o))
+            idx = idx[np.lexsort((idx, row_of))]
+        dtype = np.float32 if case % 5 == 3 else np.float64
+        val = rng.uniform(0.5, 1.5, idx.size).astype(dtype)
+        x = rng.uniform(0.5, 1.5, cols).astype(dtype)
+        A = spam.CsrMatrix(rows, cols, val, idx.astype(np.uint64), off, is_sorted)
+        y = A.spmv(x)
+        ref = oracle.spmv((off, idx.astype(np.uint64), val.astype(np.float64)), x.astype(np.float64))
+        nz = ref != 0
+        assert np.all(y[~nz] == 0), f"case {case}"
+        rtol = F64_RTOL if dtype == np.float64 else 3e-5
+        if nz.any():
+            assert (np.abs(y[nz].astype(np.float64) - ref[nz]) / np.abs(ref[nz])).max() <= rtol, f"case {case}"
