@@ -985,6 +985,8 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
           t1 = clock64();
           (dense ? t_da : t_a) += t1 - t0;
           t0 = t1;
+          atomicAdd(&gstats[parts > 1 ? 11 : 12], 1ull);          // (group, batch) iterations: giant / normal rows
+          atomicAdd(&gstats[parts > 1 ? 13 : 14], (unsigned long long)total);  // products
         }
         // products per lane and round: HEAVY_U when there is enough work, fewer when the group is small so that
         // all wavefronts share it (the chain of LDS round trips per lane is what a small group waits for)
@@ -1994,6 +1996,9 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     if (dbg_heavy & 32)
       fprintf(stderr, "[spam dbg] heavy phase cycles (sum over workgroups): row-setup %llu  groupA %llu  products %llu  compaction %llu  (dense: A %llu prod %llu comp %llu)\n",
               hg[4], hg[5], hg[6], hg[7], hg[8], hg[9], hg[10]);
+    if (dbg_heavy & 32)
+      fprintf(stderr, "[spam dbg] (group, batch) iterations: giant rows %llu with %llu products, other rows %llu with %llu products; giant rows %u, other %u\n",
+              hg[11], hg[13], hg[12], hg[14], hsplit[1], hsplit[0]);
     st.heavy_dense_groups = hg[0], st.heavy_hash_groups = hg[1], st.heavy_dense_nnz = hg[2], st.heavy_hash_nnz = hg[3];
   }
   if (sort_rows == 2 && n_hnum) {
