@@ -128,6 +128,16 @@ int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y); /* device-resi
 /* What the SpMV analysis of this matrix decided (valid after the first SpMV on the handle): number of columns in the
  * L2-resident hot table (0 = disabled), the share of the entries they cover, and the number of nnz tiles. */
 int spam_spmv_plan_info(const spam_csr* a, uint64_t* hot_columns, double* hot_cover, uint64_t* tiles);
+/* XCD-sliced mode (valid after the first SpMV): when x is larger than one XCD's L2 and eight per-XCD x-tables cover
+ * clearly more gathers than one, the analysis deals the most referenced columns over 8 slabs, stores the rows of
+ * >= long_min entries as 8 slab CSRs (+ 8 partial y vectors, added in slab order) and keeps the shorter rows in a
+ * residual CSR; the first SpMV times both paths on the caller's x and keeps the faster one.  *active = 1 when the
+ * sliced path won; the other outputs describe it (rows / entries in the slabs, table slots per XCD, slots also held
+ * in LDS, share of the gathers covered by the 8 tables / by one table, the two timings in ms).  Environment:
+ * SPAM_SPMV_SLICED = 0 never, 1 decide (default), 2 always. */
+int spam_spmv_sliced_info(const spam_csr* a, int* active, uint64_t* long_rows, uint64_t* nnz_long, uint64_t* table_slots,
+                          uint64_t* lds_slots, double* cover_table, double* cover_single, double* ms_plain,
+                          double* ms_sliced);
 
 /* ---- SpGEMM: C = A B, two phases like mul_hash ----------------------------------------------
  * spam_spgemm_symbolic  = rows_to_threads' flop count (mul_hash.rs:39-50) + mul_hash_symbolic (:66-103)

@@ -137,7 +137,15 @@ class DeviceCsr:
     def spmv_plan_info(self) -> dict:
         k, cov, tiles = C.c_uint64(), C.c_double(), C.c_uint64()
         check(_lib.load().spam_spmv_plan_info(self._h, C.byref(k), C.byref(cov), C.byref(tiles)))
-        return {"hot_columns": k.value, "hot_cover": cov.value, "tiles": tiles.value}
+        info = {"hot_columns": k.value, "hot_cover": cov.value, "tiles": tiles.value}
+        act = C.c_int()
+        u = [C.c_uint64() for _ in range(4)]
+        d = [C.c_double() for _ in range(4)]
+        check(_lib.load().spam_spmv_sliced_info(self._h, C.byref(act), *[C.byref(v) for v in u], *[C.byref(v) for v in d]))
+        info["sliced"] = {"active": bool(act.value), "long_rows": u[0].value, "nnz_long": u[1].value,
+                          "table_slots_per_xcd": u[2].value, "lds_slots": u[3].value, "cover_table": d[0].value,
+                          "cover_single": d[1].value, "ms_plain": d[2].value, "ms_sliced": d[3].value}
+        return info
 
     def spmv(self, x: np.ndarray) -> np.ndarray:
         rows, cols, _, dt, _ = self.dims()

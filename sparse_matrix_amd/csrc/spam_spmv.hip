@@ -18,12 +18,26 @@
 //     second tiny kernel — deterministic, no float atomics.
 //   The row -> tile map (first row starting in each tile) depends on row_ptr only and is built once per
 //   matrix (the analysis step of CSR-adaptive), then reused by every SpMV on that handle.
+//
+// XCD-sliced mode (second half of this file): when x is larger than one XCD's 4 MB L2 a random gather that
+// misses L2 moves a whole 128-byte line over the fabric (52 G gathers/s against 245 G/s for L2 hits,
+// profiles/r01_gather_microbench.txt).  MI355X has EIGHT such L2s; tools/xcd_gather_bench.hip shows they serve
+// 230 G gathers/s from a 24-28 MB table as long as every workgroup only touches the table slice of the XCD it
+// runs on.  So the analysis deals the most referenced columns over 8 slabs (one packed x-table per XCD), splits
+// the entries of the long rows into 8 slab CSRs, and the kernel's workgroups read HW_REG_XCC_ID and pull tiles of
+// their own XCD's slab from a per-XCD queue (stealing from the others at the end, so nothing depends on the
+// placement).  Every slab yields a partial y over the long rows; a last kernel adds the 8 partials in slab order.
+// Short rows (too few entries to pay for 8 partials) stay in a residual CSR that runs through the tile kernel above.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "spam_internal.hpp"
 
 namespace spam {
+
+struct SlicedPlan;
+static void sliced_plan_free(SlicedPlan* q);
 
 struct SpmvPlan {
   uint32_t* first_owned = nullptr;  // [ntiles + 1]: first row whose start lies in tile t (rows for t = ntiles)
@@ -38,6 +52,9 @@ struct SpmvPlan {
   uint32_t* ja_hot = nullptr;       // u32[nnz]
   uint32_t* hot_cols = nullptr;     // u32[hot_k]
   void* xh = nullptr;               // T[hot_k], rebuilt from x by every SpMV
+  // XCD-sliced mode (analysis + one timing comparison on the first SpMV)
+  SlicedPlan* sliced = nullptr;     // non-null: SpMV runs sliced
+  int64_t sliced_key = -1;          // configuration the decision was taken for (-1: not decided, 0: off)
 };
 
 void spmv_plan_free(SpmvPlan* p) {
@@ -47,6 +64,7 @@ void spmv_plan_free(SpmvPlan* p) {
   if (p->ja_hot) dev_free(p->ja_hot);
   if (p->hot_cols) dev_free(p->hot_cols);
   if (p->xh) dev_free(p->xh);
+  if (p->sliced) sliced_plan_free(p->sliced);
   delete p;
 }
 
@@ -113,25 +131,58 @@ __device__ __forceinline__ T gather_x(const T* __restrict__ x, const T* __restri
   return __builtin_nontemporal_load(x + i);
 }
 
-template <class T, class OffT, int NPT, bool NT, int HOT>
-__global__ __launch_bounds__(SPMV_TPB) void spmv_tile_kernel(const OffT* __restrict__ row_ptr,
-                                                            const uint32_t* __restrict__ col,
-                                                            const T* __restrict__ val, const T* __restrict__ x,
-                                                            const T* __restrict__ xh, T* __restrict__ y,
-                                                            const uint32_t* __restrict__ fo, T* __restrict__ carry,
-                                                            uint64_t nnz) {
-  constexpr int TILE = SPMV_TPB * NPT;
-  constexpr int MAXLONG = TILE / (SHORT_ROW + 1) + 2;
-  __shared__ T prod[TILE + TILE / 32 + 1];
-  __shared__ uint32_t long_list[MAXLONG];
-  __shared__ uint32_t n_long;
+template <class T, int HOT>
+struct GatherPlain {
+  const T* __restrict__ x;
+  const T* __restrict__ xh;
+  __device__ __forceinline__ T operator()(uint32_t c) const { return gather_x<T, HOT>(x, xh, c); }
+};
+
+template <class T, int TPB, int NPT>
+struct TileSmem {
+  static constexpr int TILE = TPB * NPT;
+  static constexpr int MAXLONG = TILE / (SHORT_ROW + 1) + 2;
+  static constexpr int RCAP = TILE >= 4096 ? 2048 : 1024;  // row_ptr values staged per pass (tile-local offsets fit 16 bits)
+  static constexpr int RK = RCAP / TPB;        // of which every thread prefetches RK while the gathers are in flight
+  static_assert(TILE <= 65535 && RCAP % TPB == 0, "tile-local offsets are kept as u16");
+  T prod[TILE + TILE / 32 + 1];
+  uint16_t rp[RCAP];
+  uint32_t long_list[MAXLONG];
+  uint32_t n_long;
+};
+
+// In-kernel phase timers (SPAM_SPMV_PROF=1, sliced kernel only; results unaffected): cycles of wave 0 summed over
+// all tiles: [0] stream + gather + products, [1] barrier, [2] short rows, [3] barrier + long rows, [4] dequeue, [5] tiles
+__device__ unsigned long long g_spmv_prof[8];
+
+// One tile of TPB*NPT entries: products into LDS, then per-row sums.  `tile_idx` is the tile's number inside the
+// (row_ptr, col, val) arrays it is given; G maps a stored column code to the x value.
+// Phase 2 never waits on global memory: the tile's slice of row_ptr (rows fo[t] .. fo[t+1]) is loaded while the
+// gathers are in flight and staged in LDS as tile-local offsets; tiles with more than RCAP-1 rows (runs of empty or
+// one-entry rows) take further passes.
+template <class T, class OffT, int TPB, int NPT, bool NT, class G, int PROF = 0>
+__device__ __forceinline__ void spmv_tile_body(TileSmem<T, TPB, NPT>& sm, const OffT* __restrict__ row_ptr,
+                                               const uint32_t* __restrict__ col, const T* __restrict__ val, const G& gx,
+                                               T* __restrict__ y, const uint32_t* __restrict__ fo, T* __restrict__ carry,
+                                               uint64_t nnz, uint32_t tile_idx) {
+  using SM = TileSmem<T, TPB, NPT>;
+  constexpr int TILE = TPB * NPT;
+  constexpr int RK = SM::RK, RCAP = SM::RCAP;
+  constexpr uint32_t CARRY = 0xFFFFFFFFu;
+  T* prod = sm.prod;
+  uint32_t* long_list = sm.long_list;
 
   const int tid = threadIdx.x;
-  const uint64_t base = (uint64_t)blockIdx.x * TILE;
+  const uint64_t base = (uint64_t)tile_idx * TILE;
   const uint32_t cnt = (uint32_t)((nnz - base) < (uint64_t)TILE ? (nnz - base) : (uint64_t)TILE);
-  if (tid == 0) n_long = 0;
+  const uint64_t end = base + cnt;
+  if (tid == 0) sm.n_long = 0;
+  long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
+  if (PROF) pt0 = clock64();
+  const uint32_t f0 = fo[tile_idx], f1 = fo[tile_idx + 1];
+  uint32_t rpv[RK];
 
-  // ---- phase 1: stream ja / a, gather x, products -> LDS ------------------------------------------
+  // ---- phase 1: stream ja / a, (row_ptr slice), gather x, products -> LDS ----------------------------
   if (cnt == TILE) {
     using VT = typename Vec4<T>::type;
     constexpr int VN = Vec4<T>::N;     // values per 16-byte load
@@ -140,7 +191,7 @@ __global__ __launch_bounds__(SPMV_TPB) void spmv_tile_kernel(const OffT* __restr
     VT v[NV][4 / VN];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const uint64_t q = base + (uint64_t)(i * SPMV_TPB + tid) * 4;
+      const uint64_t q = base + (uint64_t)(i * TPB + tid) * 4;
       if (NT) {
         c[i] = __builtin_nontemporal_load((const u32x4*)(col + q));
 #pragma unroll
@@ -151,70 +202,120 @@ __global__ __launch_bounds__(SPMV_TPB) void spmv_tile_kernel(const OffT* __restr
         for (int j = 0; j < 4 / VN; ++j) v[i][j] = *((const VT*)(val + q) + j);
       }
     }
+    const uint32_t nv0 = f1 - f0 + 1;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+      const uint32_t i = (uint32_t)(k * TPB + tid);
+      uint64_t rv = end;
+      if (i < nv0) rv = (uint64_t)row_ptr[f0 + i];
+      rpv[k] = (uint32_t)((rv < end ? rv : end) - base);
+    }
     T xv[NV][4];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xv[i][j] = gather_x<T, HOT>(x, xh, c[i][j]);
+      for (int j = 0; j < 4; ++j) xv[i][j] = gx(c[i][j]);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int q = (i * SPMV_TPB + tid) * 4;
+      const int q = (i * TPB + tid) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) prod[pad_idx(q + j)] = v[i][j / VN][j % VN] * xv[i][j];
     }
   } else {
-    for (uint32_t q = tid; q < cnt; q += SPMV_TPB)
-      prod[pad_idx(q)] = val[base + q] * gather_x<T, HOT>(x, xh, col[base + q]);
+    const uint32_t nv0 = f1 - f0 + 1;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+      const uint32_t i = (uint32_t)(k * TPB + tid);
+      uint64_t rv = end;
+      if (i < nv0) rv = (uint64_t)row_ptr[f0 + i];
+      rpv[k] = (uint32_t)((rv < end ? rv : end) - base);
+    }
+    for (uint32_t q = tid; q < cnt; q += TPB) prod[pad_idx(q)] = val[base + q] * gx(col[base + q]);
   }
+#pragma unroll
+  for (int k = 0; k < RK; ++k) sm.rp[k * TPB + tid] = (uint16_t)rpv[k];
+  if (PROF == 2) return;  // experiment: phase 1 only (wrong results)
+  if (PROF) pt1 = clock64();
   __syncthreads();
+  if (PROF) pt2 = clock64();
 
-  // ---- phase 2: per-row sums -----------------------------------------------------------------------
-  const uint32_t f0 = fo[blockIdx.x], f1 = fo[blockIdx.x + 1];
-  const uint64_t end = base + cnt;
-  const bool has_carry = f0 > 0 && (uint64_t)row_ptr[f0] > base;  // row f0-1 started before this tile
-  if (has_carry && tid == 0) long_list[atomicAdd(&n_long, 1u)] = 0xFFFFFFFFu;
-  for (uint32_t r = f0 + tid; r < f1; r += SPMV_TPB) {
-    const uint64_t s = row_ptr[r];
-    uint64_t e = row_ptr[r + 1];
-    e = e < end ? e : end;
-    const uint32_t len = (uint32_t)(e - s);
-    if (len <= SHORT_ROW) {
-      T acc = T(0);
-      if (len) {
-        int p = (int)(s - base);
-        acc = prod[pad_idx(p)];
-        for (uint32_t k = 1; k < len; ++k) acc += prod[pad_idx(p + (int)k)];
-      }
-      y[r] = acc;
-    } else {
-      long_list[atomicAdd(&n_long, 1u)] = r;
-    }
-  }
-  __syncthreads();
+  // ---- phase 2: per-row sums, everything from LDS -------------------------------------------------------
+  const uint32_t nv = f1 - f0 + 1;  // row_ptr values of this tile: rows f0 .. f1 - 1 plus the closing offset
   const int lane = tid & 63, wave = tid >> 6;
-  const uint32_t nl = n_long;
-  for (uint32_t i = wave; i < nl; i += SPMV_TPB / 64) {
-    const uint32_t r = long_list[i];
-    uint64_t s, e;
-    if (r == 0xFFFFFFFFu) {
-      s = base;
-      e = row_ptr[f0];
-    } else {
-      s = row_ptr[r];
-      e = row_ptr[r + 1];
+  uint32_t row0 = 0;                // rows finished in earlier passes
+  for (;;) {
+    const uint32_t n = (nv - row0) < (uint32_t)RCAP ? (nv - row0) : (uint32_t)RCAP;  // staged values rp[0 .. n)
+    const uint32_t nr = n - 1;                                                       // complete rows of this pass
+    // row f0-1 started in an earlier tile: its piece [0, rp[0]) goes to carry[tile]
+    if (row0 == 0 && tid == 0 && f0 > 0 && sm.rp[0] > 0) long_list[atomicAdd(&sm.n_long, 1u)] = CARRY;
+    for (uint32_t i = tid; i < nr; i += TPB) {
+      const uint32_t s = sm.rp[i], e = sm.rp[i + 1];
+      const uint32_t len = e - s;
+      if (len <= SHORT_ROW) {
+        T acc = T(0);
+        if (len) {
+          acc = prod[pad_idx((int)s)];
+          for (uint32_t k = 1; k < len; ++k) acc += prod[pad_idx((int)(s + k))];
+        }
+        y[f0 + row0 + i] = acc;
+      } else {
+        long_list[atomicAdd(&sm.n_long, 1u)] = i;
+      }
     }
-    e = e < end ? e : end;
-    T acc = T(0);
-    for (int p = (int)(s - base) + lane, pe = (int)(e - base); p < pe; p += 64) acc += prod[pad_idx(p)];
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      if (r == 0xFFFFFFFFu)
-        carry[blockIdx.x] = acc;
-      else
-        y[r] = acc;
+    if (PROF && row0 == 0) pt3 = clock64();
+    __syncthreads();
+    const uint32_t nl = sm.n_long;
+    for (uint32_t j = wave; j < nl; j += TPB / 64) {
+      const uint32_t i = long_list[j];
+      uint32_t s = 0, e;
+      if (i == CARRY) {
+        e = sm.rp[0];
+      } else {
+        s = sm.rp[i];
+        e = sm.rp[i + 1];
+      }
+      T acc = T(0);
+      for (int p = (int)s + lane, pe = (int)e; p < pe; p += 64) acc += prod[pad_idx(p)];
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        if (i == CARRY)
+          carry[tile_idx] = acc;
+        else
+          y[f0 + row0 + i] = acc;
+      }
     }
+    row0 += nr;
+    if (row0 + 1 >= nv) break;
+    __syncthreads();  // everyone is done with rp / long_list of this pass
+    if (tid == 0) sm.n_long = 0;
+    const uint32_t n2 = (nv - row0) < (uint32_t)RCAP ? (nv - row0) : (uint32_t)RCAP;
+    for (uint32_t i = tid; i < n2; i += TPB) {
+      const uint64_t rv = (uint64_t)row_ptr[f0 + row0 + i];
+      sm.rp[i] = (uint16_t)((rv < end ? rv : end) - base);
+    }
+    __syncthreads();
   }
+  if (PROF && tid == 0) {
+    const long long pt4 = clock64();
+    atomicAdd(&g_spmv_prof[0], (unsigned long long)(pt1 - pt0));
+    atomicAdd(&g_spmv_prof[1], (unsigned long long)(pt2 - pt1));
+    atomicAdd(&g_spmv_prof[2], (unsigned long long)(pt3 - pt2));
+    atomicAdd(&g_spmv_prof[3], (unsigned long long)(pt4 - pt3));
+    atomicAdd(&g_spmv_prof[5], 1ull);
+  }
+}
+
+template <class T, class OffT, int NPT, bool NT, int HOT>
+__global__ __launch_bounds__(SPMV_TPB) void spmv_tile_kernel(const OffT* __restrict__ row_ptr,
+                                                            const uint32_t* __restrict__ col,
+                                                            const T* __restrict__ val, const T* __restrict__ x,
+                                                            const T* __restrict__ xh, T* __restrict__ y,
+                                                            const uint32_t* __restrict__ fo, T* __restrict__ carry,
+                                                            uint64_t nnz) {
+  __shared__ TileSmem<T, SPMV_TPB, NPT> sm;
+  const GatherPlain<T, HOT> gx{x, xh};
+  spmv_tile_body<T, OffT, SPMV_TPB, NPT, NT>(sm, row_ptr, col, val, gx, y, fo, carry, nnz, blockIdx.x);
 }
 
 // Fold the pieces of rows that span several tiles, in tile order.
@@ -362,47 +463,668 @@ static int env_int(const char* name, int dflt) {
   return s ? atoi(s) : dflt;
 }
 
-template <class T, class OffT>
-static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, hipStream_t s) {
-  if (a->nnz == 0) {
-    fill_zero_kernel<T><<<(unsigned)((a->rows + 255) / 256), 256, 0, s>>>(y, a->rows);
+// Smallest threshold t whose column set {cnt >= t} has at most kmax members; n = their number, mass = their total count.
+static int bisect_threshold(const uint32_t* cnt, uint32_t cols, uint64_t kmax, hipStream_t s, uint32_t* t_out,
+                            uint64_t* n_out, uint64_t* mass_out) {
+  DevBuf out;
+  SPAM_TRY(out.alloc(16));
+  uint32_t lo = 1, hi = 0x7FFFFFFFu;
+  unsigned long long best[2] = {0, 0};
+  const unsigned g = (unsigned)std::min<uint64_t>((cols + 255) / 256, 4096);
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    unsigned long long h[2];
+    SPAM_HIP_TRY(hipMemsetAsync(out.p, 0, 16, s));
+    count_ge_kernel<<<g, 256, 0, s>>>(cnt, cols, mid, out.as<unsigned long long>());
     SPAM_CHECK_LAUNCH();
+    SPAM_HIP_TRY(hipMemcpyAsync(h, out.p, 16, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+    if (h[0] <= kmax) {
+      hi = mid;
+      best[0] = h[0], best[1] = h[1];
+    } else {
+      lo = mid + 1;
+    }
+  }
+  *t_out = lo;
+  *n_out = best[0];
+  *mass_out = best[1];
+  return SPAM_OK;
+}
+
+// =====================================================================================================
+// XCD-sliced SpMV
+// =====================================================================================================
+constexpr int NSLAB = 8;                      // one slab per XCD of MI355X
+constexpr uint32_t NO_DEST = 0xFFFFFFFFu;
+constexpr int HEAD_STRIDE = 64;               // u32 words between two queue heads: one 256-byte block each, so the
+                                              // eight XCDs' dequeue atomics do not serialise on one line
+
+template <class T>
+struct SlabDesc {
+  const uint32_t* row_ptr;  // u32[nl + 1]: entry offsets of the compact long rows inside this slab
+  const uint32_t* col;      // column codes: < S table slot, otherwise S + column
+  const T* val;
+  const T* xh;              // this slab's packed x table, S slots
+  T* y;                     // partial sums over the long rows, T[nl]
+  const uint32_t* fo;       // first_owned of this slab's tiles
+  T* carry;
+  uint32_t nnz, ntiles;
+};
+
+struct SlicedPlan {
+  int mode_built = 0;           // the configuration key this plan was built for
+  uint32_t S = 0, L = 0;        // table slots per slab; the first L of them are also kept in LDS
+  uint32_t nl = 0;              // long rows
+  uint32_t long_min = 0;        // rows with >= long_min entries are long
+  int tpb = 256, npt = 16;
+  double cover_table = 0, cover_single = 0;
+  uint64_t n_table_cols = 0, nnz_long = 0;
+  uint32_t total_tiles = 0;
+  unsigned grid = 0;
+  uint32_t* dest = nullptr;       // u32[cols]: flat table index of a table column, NO_DEST otherwise
+  void* xh = nullptr;             // T[NSLAB * S]
+  uint32_t* long_rows = nullptr;  // u32[nl]
+  uint32_t* srow_ptr = nullptr;   // u32[NSLAB][nl + 1]
+  uint32_t* scol = nullptr;
+  void* sval = nullptr;
+  uint32_t* sfo = nullptr;
+  void* scarry = nullptr;
+  void* partial = nullptr;        // T[NSLAB][nl]
+  void* descs = nullptr;          // SlabDesc<T>[NSLAB] on the device
+  uint32_t* heads = nullptr;      // u32[NSLAB] tile queue heads
+  spam_csr* residual = nullptr;   // the short rows (long rows empty), same shape as the matrix
+  float ms_plain = 0, ms_sliced = 0;
+};
+
+static void sliced_plan_free(SlicedPlan* q) {
+  if (!q) return;
+  void* ptrs[] = {q->dest, q->xh, q->long_rows, q->srow_ptr, q->scol, q->sval, q->sfo, q->scarry, q->partial, q->descs, q->heads};
+  for (void* p : ptrs)
+    if (p) dev_free(p);
+  if (q->residual) {
+    spam_csr* r = q->residual;
+    if (r->spmv_plan) spmv_plan_free(r->spmv_plan);
+    if (r->row_ptr32) dev_free(r->row_ptr32);
+    if (r->col_idx) dev_free(r->col_idx);
+    if (r->vals) dev_free(r->vals);
+    delete r;
+  }
+  delete q;
+}
+
+__device__ __forceinline__ uint32_t xcc_id() {
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+  return v;
+}
+
+// MODE 0: table slots from the slab table (or LDS), cold columns by a non-temporal load from x.
+// MODE 1 (experiment, wrong results): cold codes wrapped into the table.  MODE 2: one load, per-lane base select.
+template <class T, int MODE = 0>
+struct GatherSliced {
+  const T* __restrict__ x;
+  const T* __restrict__ xh;
+  const T* lds;
+  uint32_t S, L;
+  __device__ __forceinline__ T operator()(uint32_t c) const {
+    if (MODE == 1) return xh[c < S ? c : c % S];
+    if (MODE == 2) {
+      const T* b = c < S ? xh + c : x + (c - S);
+      return *b;
+    }
+    if (c < L) return lds[c];
+    if (c < S) return xh[c];
+    return __builtin_nontemporal_load(x + (c - S));
+  }
+};
+
+// Persistent workgroups: each learns the XCD it runs on, works through that XCD's slab queue (its gathers then hit
+// the slab table in the local L2, the hottest L slots in LDS), and afterwards helps the other slabs finish.
+template <class T, int TPB, int NPT, bool LDS, int PROF = 0>
+__global__ __launch_bounds__(TPB) void spmv_sliced_kernel(const SlabDesc<T>* __restrict__ descs, const T* __restrict__ x,
+                                                         uint32_t S, uint32_t L, uint32_t* __restrict__ heads) {
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  __shared__ TileSmem<T, TPB, NPT> sm;
+  __shared__ uint32_t s_t;
+  const uint32_t home = xcc_id() & (NSLAB - 1);
+  T* tab = reinterpret_cast<T*>(dyn_lds);
+  if (LDS) {
+    const T* src = descs[home].xh;
+    for (uint32_t j = threadIdx.x; j < L; j += TPB) tab[j] = src[j];
+  }
+  for (uint32_t d = 0; d < NSLAB; ++d) {
+    const uint32_t k = (home + d) & (NSLAB - 1);
+    const SlabDesc<T> sd = descs[k];
+    constexpr int GM = PROF >= 3 ? PROF - 2 : 0;
+    const GatherSliced<T, GM> gx{x, sd.xh, tab, S, (LDS && d == 0) ? L : 0u};
+    uint32_t* head = heads + k * HEAD_STRIDE;
+    if (threadIdx.x == 0) s_t = atomicAdd(head, 1u);
+    __syncthreads();
+    uint32_t t = s_t;
+    __syncthreads();
+    while (t < sd.ntiles) {
+      uint32_t nxt = 0;
+      if (threadIdx.x == 0) nxt = atomicAdd(head, 1u);  // the next ticket travels while this tile is processed
+      spmv_tile_body<T, uint32_t, TPB, NPT, true, GatherSliced<T, GM>, (PROF >= 3 ? 0 : PROF)>(sm, sd.row_ptr, sd.col, sd.val, gx, sd.y, sd.fo, sd.carry,
+                                                                          sd.nnz, t);
+      long long q0 = 0;
+      if (PROF) q0 = clock64();
+      if (threadIdx.x == 0) s_t = nxt;
+      __syncthreads();
+      t = s_t;
+      __syncthreads();
+      if (PROF && threadIdx.x == 0) atomicAdd(&g_spmv_prof[4], (unsigned long long)(clock64() - q0));
+    }
+  }
+}
+
+template <class T>
+__global__ void sliced_fixup_kernel(const SlabDesc<T>* __restrict__ descs, uint32_t tile) {
+  const SlabDesc<T> sd = descs[blockIdx.y];
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 || t >= sd.ntiles) return;
+  const uint32_t f = sd.fo[t];
+  if (f == 0) return;
+  const uint64_t rs = sd.row_ptr[f];
+  if (!(rs > t * tile)) return;
+  if (sd.fo[t - 1] == f) return;
+  T acc = sd.y[f - 1];
+  for (uint64_t u = t; u < sd.ntiles && sd.fo[u] == f && rs > u * tile; ++u) acc += sd.carry[u];
+  sd.y[f - 1] = acc;
+}
+
+// y[long row] = sum of the slab partials, in slab order (deterministic)
+template <class T>
+__global__ void sliced_reduce_kernel(const T* __restrict__ partial, const uint32_t* __restrict__ long_rows, uint32_t nl,
+                                     T* __restrict__ y) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nl) return;
+  T acc = partial[i];
+#pragma unroll
+  for (int k = 1; k < NSLAB; ++k) acc += partial[(uint64_t)k * nl + i];
+  y[long_rows[i]] = acc;
+}
+
+// The rows left in the residual CSR (fewer than long_min entries): one lane per row, summed left to right — the
+// oracle's order, so these rows are bit-identical to it.  Rows that went to the slabs are empty here and get a 0
+// that the reduce kernel overwrites later on the same stream.
+template <class T, int HOT>
+__global__ __launch_bounds__(256) void spmv_short_rows_kernel(const uint32_t* __restrict__ res_ptr,
+                                                              const uint32_t* __restrict__ col, const T* __restrict__ val,
+                                                              const T* __restrict__ x, const T* __restrict__ xh,
+                                                              uint32_t rows, T* __restrict__ y) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const uint32_t s = res_ptr[r], e = res_ptr[r + 1];
+  T acc = T(0);
+  if (s < e) {
+    acc = val[s] * gather_x<T, HOT>(x, xh, col[s]);
+    for (uint32_t p = s + 1; p < e; ++p) acc += val[p] * gather_x<T, HOT>(x, xh, col[p]);
+  }
+  y[r] = acc;
+}
+
+// Rebuild the 8 slab tables from x (column order: x and dest stream, the table writes of one workgroup are
+// contiguous runs inside each slab) and reset the tile queues.
+template <class T>
+__global__ void sliced_build_tables_kernel(const T* __restrict__ x, const uint32_t* __restrict__ dest, uint32_t cols,
+                                           T* __restrict__ xh, uint32_t* __restrict__ heads) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < NSLAB) heads[i * HEAD_STRIDE] = 0;
+  if (i >= cols) return;
+  const uint32_t d = dest[i];
+  if (d != NO_DEST) xh[d] = x[i];
+}
+
+// ---- analysis kernels ---------------------------------------------------------------------------------
+__global__ void sliced_level_flags_kernel(const uint32_t* __restrict__ cnt, uint32_t cols, uint32_t t_lds, uint32_t t_tab,
+                                          uint32_t* __restrict__ f0, uint32_t* __restrict__ f1) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cols) return;
+  const uint32_t c = cnt[i];
+  f0[i] = c >= t_lds;
+  f1[i] = c >= t_tab && c < t_lds;
+}
+__device__ __forceinline__ uint32_t mix32(uint32_t v) {
+  v ^= v >> 16, v *= 0x7FEB352Du, v ^= v >> 15, v *= 0x846CA68Bu, v ^= v >> 16;
+  return v;
+}
+// Level-0 columns (LDS level) are dealt over the slabs in column order, then the level-1 columns: each group of 8
+// consecutive columns of a level gives one column to every slab, so a slab's slots rise with the column index inside
+// each level.  Which member goes to which slab is rotated by a hash of the group number: in R-MAT the popularity of
+// a column follows its low bits, and a fixed member -> slab rule hands one slab several times the entries of
+// another.  Everything else is cold (gathered from x itself) and rotated the same way.
+__global__ void sliced_assign_kernel(const uint32_t* __restrict__ f0, const uint32_t* __restrict__ f1,
+                                     const uint64_t* __restrict__ p0, const uint64_t* __restrict__ p1, uint32_t cols,
+                                     uint32_t L, uint32_t S, uint32_t line_slots, uint32_t* __restrict__ code,
+                                     uint8_t* __restrict__ slab, uint32_t* __restrict__ dest) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cols) return;
+  if (f0[i]) {
+    const uint64_t p = p0[i];
+    const uint32_t j = (uint32_t)(p / NSLAB), k = ((uint32_t)(p % NSLAB) + mix32(j)) & (NSLAB - 1);
+    code[i] = j, slab[i] = (uint8_t)k, dest[i] = k * S + j;
+  } else if (f1[i]) {
+    const uint64_t p = p1[i];
+    const uint32_t g = (uint32_t)(p / NSLAB), j = L + g, k = ((uint32_t)(p % NSLAB) + mix32(g ^ 0x9E3779B9u)) & (NSLAB - 1);
+    code[i] = j, slab[i] = (uint8_t)k, dest[i] = k * S + j;
+  } else {
+    const uint32_t c = (uint32_t)i;
+    code[i] = S + c, slab[i] = (uint8_t)((c + mix32(c >> 3)) & (NSLAB - 1)), dest[i] = NO_DEST;
+  }
+}
+__global__ void sliced_row_flags_kernel(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t long_min,
+                                        uint32_t* __restrict__ is_long, uint32_t* __restrict__ short_len) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const uint32_t len = row_ptr[r + 1] - row_ptr[r];
+  const bool lg = len >= long_min;
+  is_long[r] = lg;
+  short_len[r] = lg ? 0u : len;
+}
+__global__ void sliced_long_list_kernel(const uint32_t* __restrict__ is_long, const uint64_t* __restrict__ pos, uint32_t rows,
+                                        uint32_t* __restrict__ long_rows) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows && is_long[r]) long_rows[pos[r]] = (uint32_t)r;
+}
+// One wavefront per long row: entries per slab.
+__global__ void sliced_count_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                    const uint8_t* __restrict__ slab, const uint32_t* __restrict__ long_rows, uint32_t nl,
+                                    uint32_t* __restrict__ cnt8) {
+  const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (w >= nl) return;
+  const uint32_t r = long_rows[w];
+  const uint32_t s = row_ptr[r], e = row_ptr[r + 1];
+  uint32_t n = 0;
+  for (uint32_t p = s; p < e; p += 64) {
+    const uint32_t k = (p + lane < e) ? slab[col[p + lane]] : NSLAB;
+#pragma unroll
+    for (uint32_t kk = 0; kk < NSLAB; ++kk) {
+      const uint64_t m = __ballot(k == kk);
+      if (lane == kk) n += (uint32_t)__popcll(m);
+    }
+  }
+  if (lane < NSLAB) cnt8[(uint64_t)lane * nl + w] = n;
+}
+// One wavefront per long row: move its entries into the slab arrays, storage order kept inside every (row, slab).
+template <class T>
+__global__ void sliced_fill_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                   const T* __restrict__ val, const uint32_t* __restrict__ code,
+                                   const uint8_t* __restrict__ slab, const uint32_t* __restrict__ long_rows, uint32_t nl,
+                                   const uint32_t* __restrict__ srow_ptr, const uint64_t* __restrict__ sbase,
+                                   uint32_t* __restrict__ scol, T* __restrict__ sval) {
+  const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (w >= nl) return;
+  const uint32_t r = long_rows[w];
+  const uint32_t s = row_ptr[r], e = row_ptr[r + 1];
+  uint64_t mybase = 0;  // lane kk < 8: next free position of slab kk for this row
+  if (lane < NSLAB) mybase = sbase[lane] + srow_ptr[(uint64_t)lane * (nl + 1) + w];
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (uint32_t p = s; p < e; p += 64) {
+    const bool act = p + lane < e;
+    uint32_t c = 0, k = NSLAB;
+    T v = T(0);
+    if (act) {
+      c = col[p + lane];
+      v = val[p + lane];
+      k = slab[c];
+    }
+    uint64_t dst = 0;
+#pragma unroll
+    for (uint32_t kk = 0; kk < NSLAB; ++kk) {
+      const uint64_t m = __ballot(k == kk);
+      const uint64_t b = __shfl(mybase, (int)kk, 64);
+      if (k == kk) dst = b + (uint64_t)__popcll(m & lt);
+      if (lane == kk) mybase += (uint64_t)__popcll(m);
+    }
+    if (act) {
+      scol[dst] = code[c];
+      sval[dst] = v;
+    }
+  }
+}
+template <class T>
+__global__ void sliced_residual_fill_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                            const T* __restrict__ val, const uint32_t* __restrict__ is_long,
+                                            const uint32_t* __restrict__ res_ptr, uint32_t rows,
+                                            uint32_t* __restrict__ out_col, T* __restrict__ out_val) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows || is_long[r]) return;
+  const uint32_t s = row_ptr[r], e = row_ptr[r + 1];
+  uint32_t o = res_ptr[r];
+  for (uint32_t p = s; p < e; ++p, ++o) {
+    out_col[o] = col[p];
+    out_val[o] = val[p];
+  }
+}
+__global__ void zero_u32_kernel(uint32_t* __restrict__ p, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+template <class T, int TPB, int NPT, bool LDS>
+static int sliced_launch_variant(const SlicedPlan* q, const T* x, hipStream_t s, unsigned* grid_out) {
+  auto kern = spmv_sliced_kernel<T, TPB, NPT, LDS>;
+  const size_t dyn = LDS ? (size_t)q->L * sizeof(T) : 0;
+  if (grid_out) {
+    if (dyn > 48 * 1024) SPAM_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    int per_cu = 0, dev = 0, cus = 0;
+    SPAM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, TPB, dyn));
+    SPAM_HIP_TRY(hipGetDevice(&dev));
+    SPAM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (per_cu < 1) return set_error(SPAM_E_HIP, "sliced SpMV kernel does not fit a CU (%zu B of LDS table)", dyn);
+    const int cap = env_int("SPAM_SPMV_SLICED_WGS", 16);
+    if (per_cu > cap) per_cu = cap;
+    uint64_t g = (uint64_t)per_cu * (uint64_t)cus;
+    if (g > q->total_tiles) g = q->total_tiles;
+    if (g == 0) g = 1;
+    *grid_out = (unsigned)g;
     return SPAM_OK;
   }
-  const int npt_cfg = env_int("SPAM_SPMV_NPT", 16);  // read per call so one process can A/B variants
-  const int nt_cfg = env_int("SPAM_SPMV_NT", 1);  // non-temporal ja/a stream: keeps L2 for x (+4..6 % on random gathers)
-  const int npt = (npt_cfg == 8) ? 8 : 16;
-  const uint32_t tile = SPMV_TPB * npt;
-  spam_csr* am = const_cast<spam_csr*>(a);
-  if (!am->spmv_plan || am->spmv_plan->npt != npt) {
-    if (am->spmv_plan) spmv_plan_free(am->spmv_plan);
-    am->spmv_plan = nullptr;
-    SpmvPlan* p = new (std::nothrow) SpmvPlan();
-    if (!p) return set_error(SPAM_E_OOM, "host allocation failed");
-    p->npt = npt;
-    p->ntiles = (a->nnz + tile - 1) / tile;
-    DevBuf fo, ca;
-    if (int e = fo.alloc((p->ntiles + 1) * 4)) {
-      delete p;
-      return e;
+  kern<<<q->grid, TPB, dyn, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+template <class T>
+static int sliced_dispatch(const SlicedPlan* q, const T* x, hipStream_t s, unsigned* grid_out) {
+  if (!grid_out && q->tpb == 256 && q->npt == 16 && !q->L) {
+    const int prof = env_int("SPAM_SPMV_PROF", 0);
+    if (prof == 2) {  // experiment: phase 1 only (wrong results)
+      spmv_sliced_kernel<T, 256, 16, false, 2><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+      SPAM_CHECK_LAUNCH();
+      return SPAM_OK;
     }
-    if (int e = ca.alloc(p->ntiles * sizeof(T))) {
-      delete p;
-      return e;
+    if (prof == 3 || prof == 4) {  // experiments on the gather form
+      if (prof == 3) spmv_sliced_kernel<T, 256, 16, false, 3><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+      else spmv_sliced_kernel<T, 256, 16, false, 4><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+      SPAM_CHECK_LAUNCH();
+      return SPAM_OK;
     }
-    p->first_owned = (uint32_t*)fo.release();
-    p->carry = ca.release();
-    spmv_first_owned_kernel<OffT><<<(unsigned)((p->ntiles + 1 + 255) / 256), 256, 0, s>>>(
-        row_ptr, (uint32_t)a->rows, tile, p->ntiles, p->first_owned);
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) {
-      spmv_plan_free(p);
-      return set_error(SPAM_E_HIP, "spmv_first_owned_kernel: %s", hipGetErrorString(le));
+    if (prof == 1) {
+      unsigned long long h[8] = {0};
+      SPAM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_prof), h, sizeof(h)));
+      spmv_sliced_kernel<T, 256, 16, false, 1><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+      SPAM_CHECK_LAUNCH();
+      SPAM_HIP_TRY(hipStreamSynchronize(s));
+      SPAM_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_spmv_prof), sizeof(h)));
+      fprintf(stderr, "[spam] sliced SpMV phase cycles per tile (wave 0): stream+gather %.0f, barrier %.0f, short rows %.0f, "
+              "barrier+long rows %.0f, dequeue %.0f; tiles %llu, grid %u\n", (double)h[0] / h[5], (double)h[1] / h[5],
+              (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], h[5], q->grid);
+      return SPAM_OK;
     }
-    am->spmv_plan = p;
   }
+#define SPAM_SLICED_VARIANT(TPB_, NPT_)                                                         \
+  if (q->tpb == TPB_ && q->npt == NPT_)                                                         \
+    return q->L ? sliced_launch_variant<T, TPB_, NPT_, true>(q, x, s, grid_out)                 \
+                : sliced_launch_variant<T, TPB_, NPT_, false>(q, x, s, grid_out)
+  SPAM_SLICED_VARIANT(256, 16);
+  SPAM_SLICED_VARIANT(256, 8);
+  SPAM_SLICED_VARIANT(512, 8);
+  SPAM_SLICED_VARIANT(1024, 4);
+#undef SPAM_SLICED_VARIANT
+  return set_error(SPAM_E_INVALID, "no sliced SpMV kernel for %d threads x %d entries", q->tpb, q->npt);
+}
+
+template <class T, class OffT>
+static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, hipStream_t s, bool allow_sliced);
+
+// Build the sliced structure.  Returns SPAM_OK with *out = nullptr when the matrix does not qualify.
+template <class T>
+static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPlan** out) {
+  *out = nullptr;
+  const int slice_kb = env_int("SPAM_SPMV_SLICE_KB", 3072);   // table bytes per XCD (of its 4 MB L2)
+  const int lds_kb = env_int("SPAM_SPMV_LDS_KB", 0);          // of which kept in LDS by every workgroup
+  const uint64_t smax = (uint64_t)slice_kb * 1024 / sizeof(T);
+  uint64_t lmax = (uint64_t)lds_kb * 1024 / sizeof(T);
+  if (lmax > smax) lmax = smax;
+  if (!a->row_ptr32 || a->nnz == 0 || a->cols >= 0x7FFFFFFFull || a->rows >= 0xFFFFFFFFull || smax == 0) return SPAM_OK;
+  if (a->cols + NSLAB * (smax + 32) >= 0xFFFFFFFFull) return SPAM_OK;
+  if (!force && (a->cols * sizeof(T) <= (4u << 20) || a->nnz < (1u << 20))) return SPAM_OK;  // x fits one L2 / too small
+  const uint32_t cols = (uint32_t)a->cols, rows = (uint32_t)a->rows;
+  const unsigned gc = (unsigned)((cols + 255) / 256), gr = (unsigned)((rows + 255) / 256);
+
+  // -- columns: histogram, level thresholds --------------------------------------------------------------
+  DevBuf cnt;
+  SPAM_TRY(cnt.alloc((uint64_t)cols * 4));
+  SPAM_HIP_TRY(hipMemsetAsync(cnt.p, 0, (uint64_t)cols * 4, s));
+  col_count_kernel<<<8192, 256, 0, s>>>(a->col_idx, a->nnz, cnt.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  uint32_t t_tab = 1, t_lds = 0x7FFFFFFFu, t_single = 1;
+  uint64_t n_tab = 0, m_tab = 0, n_lds = 0, m_lds = 0, n_single = 0, m_single = 0;
+  SPAM_TRY(bisect_threshold(cnt.as<uint32_t>(), cols, NSLAB * smax, s, &t_tab, &n_tab, &m_tab));
+  SPAM_TRY(bisect_threshold(cnt.as<uint32_t>(), cols, smax, s, &t_single, &n_single, &m_single));
+  if (lmax) SPAM_TRY(bisect_threshold(cnt.as<uint32_t>(), cols, NSLAB * lmax, s, &t_lds, &n_lds, &m_lds));
+  if (n_lds == 0) t_lds = 0x7FFFFFFFu;
+  const double cover_tab = (double)m_tab / (double)a->nnz, cover_single = (double)m_single / (double)a->nnz;
+  if (!force && cover_tab - cover_single < 0.10) return SPAM_OK;  // eight tables would hold little more than one
+  const uint32_t line_slots = 128 / sizeof(T);
+  uint32_t L = (uint32_t)((n_lds + NSLAB - 1) / NSLAB);
+  L = (L + line_slots - 1) / line_slots * line_slots;  // the level-1 part of a slab table starts on a 128-byte line
+  uint32_t S1 = (uint32_t)((n_tab - n_lds + NSLAB - 1) / NSLAB);
+  S1 = std::max<uint32_t>(line_slots, (S1 + line_slots - 1) / line_slots * line_slots);
+  const uint32_t S = L + S1;
+
+  SlicedPlan* q = new (std::nothrow) SlicedPlan();
+  if (!q) return set_error(SPAM_E_OOM, "host allocation failed");
+  struct Guard {
+    SlicedPlan* q;
+    ~Guard() { if (q) sliced_plan_free(q); }
+  } guard{q};
+  q->S = S, q->L = L, q->cover_table = cover_tab, q->cover_single = cover_single, q->n_table_cols = n_tab;
+  {
+    const int t = env_int("SPAM_SPMV_SLICED_TPB", 256), n = env_int("SPAM_SPMV_SLICED_NPT", 0);
+    q->tpb = t == 1024 ? 1024 : (t == 512 ? 512 : 256);
+    q->npt = q->tpb == 1024 ? 4 : (q->tpb == 512 ? 8 : (n == 8 ? 8 : 16));
+  }
+  const uint32_t tile = (uint32_t)(q->tpb * q->npt);
+  {
+    // rows worth 8 partials: a long row costs ~160 B of partial/row_ptr traffic, a short-path entry that misses
+    // the single table costs ~15 ps more than an L2 hit -> long when len * miss > ~1.8
+    const double miss = std::max(0.05, 1.0 - cover_single);
+    int lm = (int)std::ceil(1.8 / miss);
+    lm = std::min(64, std::max(2, lm));
+    q->long_min = (uint32_t)env_int("SPAM_SPMV_LONG", lm);
+    if (q->long_min < 1) q->long_min = 1;
+  }
+
+  DevBuf f0, f1, p0, p1, tmp, code, slab, dest;
+  SPAM_TRY(f0.alloc((uint64_t)cols * 4));
+  SPAM_TRY(f1.alloc((uint64_t)cols * 4));
+  SPAM_TRY(p0.alloc(((uint64_t)cols + 1) * 8));
+  SPAM_TRY(p1.alloc(((uint64_t)cols + 1) * 8));
+  SPAM_TRY(tmp.alloc(scan_tmp_bytes(std::max<uint64_t>(cols, rows))));
+  SPAM_TRY(code.alloc((uint64_t)cols * 4));
+  SPAM_TRY(slab.alloc((uint64_t)cols));
+  SPAM_TRY(dest.alloc((uint64_t)cols * 4));
+  sliced_level_flags_kernel<<<gc, 256, 0, s>>>(cnt.as<uint32_t>(), cols, t_lds, t_tab, f0.as<uint32_t>(), f1.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  SPAM_TRY(scan_u32_to_u64(f0.as<uint32_t>(), cols, p0.as<uint64_t>(), tmp.p, s));
+  SPAM_TRY(scan_u32_to_u64(f1.as<uint32_t>(), cols, p1.as<uint64_t>(), tmp.p, s));
+  sliced_assign_kernel<<<gc, 256, 0, s>>>(f0.as<uint32_t>(), f1.as<uint32_t>(), p0.as<uint64_t>(), p1.as<uint64_t>(), cols, L, S,
+                                          line_slots, code.as<uint32_t>(), slab.as<uint8_t>(), dest.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+
+  // -- rows: long / short ----------------------------------------------------------------------------------
+  DevBuf is_long, short_len, posl, res64, res32;
+  SPAM_TRY(is_long.alloc((uint64_t)rows * 4));
+  SPAM_TRY(short_len.alloc((uint64_t)rows * 4));
+  SPAM_TRY(posl.alloc(((uint64_t)rows + 1) * 8));
+  SPAM_TRY(res64.alloc(((uint64_t)rows + 1) * 8));
+  SPAM_TRY(res32.alloc(((uint64_t)rows + 1) * 4));
+  sliced_row_flags_kernel<<<gr, 256, 0, s>>>(a->row_ptr32, rows, q->long_min, is_long.as<uint32_t>(), short_len.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  SPAM_TRY(scan_u32_to_u64(is_long.as<uint32_t>(), rows, posl.as<uint64_t>(), tmp.p, s));
+  SPAM_TRY(scan_u32_to_u64(short_len.as<uint32_t>(), rows, res64.as<uint64_t>(), tmp.p, s));
+  SPAM_TRY(narrow_row_ptr(res64.as<uint64_t>(), (uint64_t)rows + 1, res32.as<uint32_t>(), s));
+  uint64_t nl64 = 0, nnz_res = 0;
+  SPAM_HIP_TRY(hipMemcpyAsync(&nl64, posl.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(&nnz_res, res64.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  if (nl64 == 0) return SPAM_OK;  // nothing to slice
+  const uint32_t nl = (uint32_t)nl64;
+  q->nl = nl;
+  q->nnz_long = a->nnz - nnz_res;
+  DevBuf long_rows;
+  SPAM_TRY(long_rows.alloc((uint64_t)nl * 4));
+  sliced_long_list_kernel<<<gr, 256, 0, s>>>(is_long.as<uint32_t>(), posl.as<uint64_t>(), rows, long_rows.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+
+  // -- slab CSRs over the long rows ------------------------------------------------------------------------
+  DevBuf cnt8, sc64, srow, sbase_d;
+  SPAM_TRY(cnt8.alloc((uint64_t)NSLAB * nl * 4));
+  SPAM_TRY(sc64.alloc(((uint64_t)nl + 1) * 8));
+  SPAM_TRY(srow.alloc((uint64_t)NSLAB * (nl + 1) * 4));
+  SPAM_TRY(sbase_d.alloc(NSLAB * 8));
+  const unsigned gw = (unsigned)(((uint64_t)nl * 64 + 255) / 256);
+  sliced_count_kernel<<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, slab.as<uint8_t>(), long_rows.as<uint32_t>(), nl,
+                                         cnt8.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  DevBuf tmp2;
+  SPAM_TRY(tmp2.alloc(scan_tmp_bytes(nl)));
+  uint64_t ne[NSLAB];
+  for (int k = 0; k < NSLAB; ++k) {
+    SPAM_TRY(scan_u32_to_u64(cnt8.as<uint32_t>() + (uint64_t)k * nl, nl, sc64.as<uint64_t>(), tmp2.p, s));
+    SPAM_TRY(narrow_row_ptr(sc64.as<uint64_t>(), (uint64_t)nl + 1, srow.as<uint32_t>() + (uint64_t)k * (nl + 1), s));
+    SPAM_HIP_TRY(hipMemcpyAsync(&ne[k], sc64.as<uint64_t>() + nl, 8, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+  }
+  uint64_t sbase[NSLAB + 1];
+  uint32_t tile_base[NSLAB + 1];
+  sbase[0] = 0, tile_base[0] = 0;
+  for (int k = 0; k < NSLAB; ++k) {
+    sbase[k + 1] = (sbase[k] + ne[k] + 3) & ~3ull;  // 16-byte vector loads start aligned in every slab
+    tile_base[k + 1] = tile_base[k] + (uint32_t)((ne[k] + tile - 1) / tile);
+  }
+  q->total_tiles = tile_base[NSLAB];
+  SPAM_HIP_TRY(hipMemcpyAsync(sbase_d.p, sbase, NSLAB * 8, hipMemcpyHostToDevice, s));
+  DevBuf scol, sval, sfo, scarry, partial, xh, descs, heads;
+  SPAM_TRY(scol.alloc((sbase[NSLAB] + 4) * 4));
+  SPAM_TRY(sval.alloc((sbase[NSLAB] + 4) * sizeof(T)));
+  SPAM_TRY(sfo.alloc(((uint64_t)q->total_tiles + NSLAB) * 4));
+  SPAM_TRY(scarry.alloc(((uint64_t)q->total_tiles + 1) * sizeof(T)));
+  SPAM_TRY(partial.alloc((uint64_t)NSLAB * nl * sizeof(T)));
+  SPAM_TRY(xh.alloc((uint64_t)NSLAB * S * sizeof(T)));
+  SPAM_TRY(descs.alloc(NSLAB * sizeof(SlabDesc<T>)));
+  SPAM_TRY(heads.alloc(NSLAB * HEAD_STRIDE * 4));
+  SPAM_HIP_TRY(hipMemsetAsync(xh.p, 0, (uint64_t)NSLAB * S * sizeof(T), s));  // unused slots stay defined
+  SPAM_HIP_TRY(hipMemsetAsync(partial.p, 0, (uint64_t)NSLAB * nl * sizeof(T), s));  // a slab without entries never writes
+  sliced_fill_kernel<T><<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, code.as<uint32_t>(), slab.as<uint8_t>(),
+                                           long_rows.as<uint32_t>(), nl, srow.as<uint32_t>(), sbase_d.as<uint64_t>(),
+                                           scol.as<uint32_t>(), sval.as<T>());
+  SPAM_CHECK_LAUNCH();
+  SlabDesc<T> hd[NSLAB];
+  for (int k = 0; k < NSLAB; ++k) {
+    const uint32_t nt = tile_base[k + 1] - tile_base[k];
+    uint32_t* fo_k = sfo.as<uint32_t>() + tile_base[k] + k;  // ntiles + 1 entries each
+    hd[k].row_ptr = srow.as<uint32_t>() + (uint64_t)k * (nl + 1);
+    hd[k].col = scol.as<uint32_t>() + sbase[k];
+    hd[k].val = sval.as<T>() + sbase[k];
+    hd[k].xh = xh.as<T>() + (uint64_t)k * S;
+    hd[k].y = partial.as<T>() + (uint64_t)k * nl;
+    hd[k].fo = fo_k;
+    hd[k].carry = scarry.as<T>() + tile_base[k];
+    hd[k].nnz = (uint32_t)ne[k];
+    hd[k].ntiles = nt;
+    spmv_first_owned_kernel<uint32_t><<<(nt + 1 + 255) / 256, 256, 0, s>>>(hd[k].row_ptr, nl, tile, nt, fo_k);
+    SPAM_CHECK_LAUNCH();
+  }
+  SPAM_HIP_TRY(hipMemcpyAsync(descs.p, hd, sizeof(hd), hipMemcpyHostToDevice, s));
+
+  // -- residual CSR: the short rows --------------------------------------------------------------------------
+  spam_csr* res = new (std::nothrow) spam_csr();
+  if (!res) return set_error(SPAM_E_OOM, "host allocation failed");
+  q->residual = res;
+  res->rows = a->rows, res->cols = a->cols, res->nnz = nnz_res, res->dtype = a->dtype, res->is_sorted = a->is_sorted;
+  {
+    DevBuf rc, rv;
+    SPAM_TRY(rc.alloc((nnz_res + 4) * 4));
+    SPAM_TRY(rv.alloc((nnz_res + 4) * sizeof(T)));
+    sliced_residual_fill_kernel<T><<<gr, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, is_long.as<uint32_t>(),
+                                                      res32.as<uint32_t>(), rows, rc.as<uint32_t>(), rv.as<T>());
+    SPAM_CHECK_LAUNCH();
+    res->row_ptr32 = (uint32_t*)res32.release();
+    res->col_idx = (uint32_t*)rc.release();
+    res->vals = rv.release();
+  }
+  SPAM_HIP_TRY(hipStreamSynchronize(s));  // host-side descriptor arrays and temporaries go out of scope
+  q->dest = (uint32_t*)dest.release();
+  q->xh = xh.release();
+  q->long_rows = (uint32_t*)long_rows.release();
+  q->srow_ptr = (uint32_t*)srow.release();
+  q->scol = (uint32_t*)scol.release();
+  q->sval = sval.release();
+  q->sfo = (uint32_t*)sfo.release();
+  q->scarry = scarry.release();
+  q->partial = partial.release();
+  q->descs = descs.release();
+  q->heads = (uint32_t*)heads.release();
+  SPAM_TRY(sliced_dispatch<T>(q, nullptr, s, &q->grid));
+  guard.q = nullptr;
+  *out = q;
+  return SPAM_OK;
+}
+
+// Short rows: their own hot-column table (analysed on the residual's histogram), one lane per row.
+template <class T>
+static int residual_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, hipStream_t s) {
+  spam_csr* res = q->residual;
+  if (!res->spmv_plan) {
+    res->spmv_plan = new (std::nothrow) SpmvPlan();  // only the hot-column part is used
+    if (!res->spmv_plan) return set_error(SPAM_E_OOM, "host allocation failed");
+  }
+  SpmvPlan* pm = res->spmv_plan;
+  const int hot_cfg = env_int("SPAM_SPMV_HOT", 2);
+  const int hot_kb = hot_cfg ? env_int("SPAM_SPMV_HOT_KB", 3072) : 0;
+  if (pm->hot_kb != hot_kb) {
+    if (pm->ja_hot) dev_free(pm->ja_hot);
+    if (pm->hot_cols) dev_free(pm->hot_cols);
+    if (pm->xh) dev_free(pm->xh);
+    pm->ja_hot = pm->hot_cols = nullptr;
+    pm->xh = nullptr;
+    SPAM_TRY(spmv_hot_analyse<T>(res, pm, hot_kb, s));
+  }
+  const uint32_t rows = (uint32_t)a->rows;
+  const unsigned g = (rows + 255) / 256;
+  if (pm->hot_k) {
+    xh_build_kernel<T><<<(pm->hot_k + 255) / 256, 256, 0, s>>>(x, pm->hot_cols, pm->hot_k, (T*)pm->xh);
+    SPAM_CHECK_LAUNCH();
+    spmv_short_rows_kernel<T, 2><<<g, 256, 0, s>>>(res->row_ptr32, pm->ja_hot, (const T*)res->vals, x, (const T*)pm->xh,
+                                                   rows, y);
+  } else {
+    spmv_short_rows_kernel<T, 0><<<g, 256, 0, s>>>(res->row_ptr32, res->col_idx, (const T*)res->vals, x, nullptr,
+                                                   rows, y);
+  }
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+template <class T>
+static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, hipStream_t s) {
+  const uint32_t cols = (uint32_t)a->cols;
+  sliced_build_tables_kernel<T><<<(cols + 255) / 256, 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads);
+  SPAM_CHECK_LAUNCH();
+  SPAM_TRY(residual_run<T>(a, q, x, y, s));
+  SPAM_TRY(sliced_dispatch<T>(q, x, s, nullptr));
+  const uint32_t tile = (uint32_t)(q->tpb * q->npt);
+  uint32_t max_tiles = (q->total_tiles + NSLAB - 1);  // >= any slab's tile count
+  sliced_fixup_kernel<T><<<dim3((max_tiles + 255) / 256, NSLAB), 256, 0, s>>>((const SlabDesc<T>*)q->descs, tile);
+  SPAM_CHECK_LAUNCH();
+  sliced_reduce_kernel<T><<<(q->nl + 255) / 256, 256, 0, s>>>((const T*)q->partial, q->long_rows, q->nl, y);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+// ---- the plain path ---------------------------------------------------------------------------------------
+template <class T, class OffT>
+static int plain_run(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, hipStream_t s) {
+  const int nt_cfg = env_int("SPAM_SPMV_NT", 1);  // non-temporal ja/a stream: keeps L2 for x (+4..6 % on random gathers)
   const int hot_cfg = env_int("SPAM_SPMV_HOT", 2);        // 0 off, 1 per-lane base select, 2 cold gathers non-temporal
   const int hot_kb = hot_cfg ? env_int("SPAM_SPMV_HOT_KB", 3072) : 0;  // of the 4 MB L2 per XCD
+  spam_csr* am = const_cast<spam_csr*>(a);
   if (am->spmv_plan->hot_kb != hot_kb) {
     SpmvPlan* pm = am->spmv_plan;
     if (pm->ja_hot) dev_free(pm->ja_hot);
@@ -413,6 +1135,8 @@ static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, 
     SPAM_TRY(spmv_hot_analyse<T>(a, pm, hot_kb, s));
   }
   const SpmvPlan* p = a->spmv_plan;
+  const int npt = p->npt;
+  const uint32_t tile = SPMV_TPB * npt;
   const unsigned grid = (unsigned)p->ntiles;
   const int hot = p->hot_k ? hot_cfg : 0;
   const uint32_t* col = hot ? p->ja_hot : a->col_idx;
@@ -448,13 +1172,103 @@ static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, 
   return SPAM_OK;
 }
 
+template <class F>
+static int time_runs(F&& run, hipStream_t s, float* ms_out) {
+  hipEvent_t e0, e1;
+  SPAM_HIP_TRY(hipEventCreate(&e0));
+  SPAM_HIP_TRY(hipEventCreate(&e1));
+  int rc = run();  // warm-up (builds lazily created pieces)
+  if (rc == SPAM_OK) {
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < 3 && rc == SPAM_OK; ++i) rc = run();
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / 3;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+template <class T, class OffT>
+static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, hipStream_t s, bool allow_sliced) {
+  if (a->nnz == 0) {
+    fill_zero_kernel<T><<<(unsigned)((a->rows + 255) / 256), 256, 0, s>>>(y, a->rows);
+    SPAM_CHECK_LAUNCH();
+    return SPAM_OK;
+  }
+  const int npt_cfg = env_int("SPAM_SPMV_NPT", 16);  // read per call so one process can A/B variants
+  const int npt = (npt_cfg == 8) ? 8 : 16;
+  const uint32_t tile = SPMV_TPB * npt;
+  spam_csr* am = const_cast<spam_csr*>(a);
+  if (!am->spmv_plan || am->spmv_plan->npt != npt) {
+    if (am->spmv_plan) spmv_plan_free(am->spmv_plan);
+    am->spmv_plan = nullptr;
+    SpmvPlan* p = new (std::nothrow) SpmvPlan();
+    if (!p) return set_error(SPAM_E_OOM, "host allocation failed");
+    p->npt = npt;
+    p->ntiles = (a->nnz + tile - 1) / tile;
+    DevBuf fo, ca;
+    if (int e = fo.alloc((p->ntiles + 1) * 4)) {
+      delete p;
+      return e;
+    }
+    if (int e = ca.alloc(p->ntiles * sizeof(T))) {
+      delete p;
+      return e;
+    }
+    p->first_owned = (uint32_t*)fo.release();
+    p->carry = ca.release();
+    spmv_first_owned_kernel<OffT><<<(unsigned)((p->ntiles + 1 + 255) / 256), 256, 0, s>>>(
+        row_ptr, (uint32_t)a->rows, tile, p->ntiles, p->first_owned);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+      spmv_plan_free(p);
+      return set_error(SPAM_E_HIP, "spmv_first_owned_kernel: %s", hipGetErrorString(le));
+    }
+    am->spmv_plan = p;
+  }
+  SpmvPlan* pm = am->spmv_plan;
+  // XCD-sliced mode: 0 never, 1 let the analysis decide and then time both paths once on this x, 2 always (tests)
+  const int sl_cfg = allow_sliced ? env_int("SPAM_SPMV_SLICED", 1) : 0;
+  int64_t sl_key = 0;
+  if (sl_cfg) {
+    const char* knobs[] = {"SPAM_SPMV_SLICE_KB", "SPAM_SPMV_LDS_KB", "SPAM_SPMV_LONG", "SPAM_SPMV_SLICED_TPB", "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS"};
+    uint64_t h = 1469598103934665603ull + (uint64_t)sl_cfg;
+    for (const char* k : knobs) h = (h ^ (uint64_t)(uint32_t)env_int(k, -1)) * 1099511628211ull;
+    sl_key = (int64_t)(h >> 1) + 1;  // never 0 or -1
+  }
+  if (pm->sliced_key != sl_key) {
+    if (pm->sliced) sliced_plan_free(pm->sliced);
+    pm->sliced = nullptr;
+    pm->sliced_key = sl_key;
+    if (sl_cfg) {
+      SlicedPlan* q = nullptr;
+      SPAM_TRY(sliced_analyse<T>(a, sl_cfg == 2, s, &q));
+      if (q && sl_cfg == 1) {  // keep it only if it is faster on this matrix
+        SPAM_TRY(time_runs([&] { return plain_run<T, OffT>(a, row_ptr, x, y, s); }, s, &q->ms_plain));
+        SPAM_TRY(time_runs([&] { return sliced_run<T>(a, q, x, y, s); }, s, &q->ms_sliced));
+        if (!(q->ms_sliced < q->ms_plain)) {
+          sliced_plan_free(q);
+          q = nullptr;
+        }
+      }
+      pm->sliced = q;
+    }
+  }
+  if (pm->sliced) return sliced_run<T>(a, pm->sliced, x, y, s);
+  return plain_run<T, OffT>(a, row_ptr, x, y, s);
+}
+
 int spmv_launch(const spam_csr* a, const void* d_x, void* d_y, hipStream_t s) {
   if (a->dtype == SPAM_F64) {
-    if (a->row_ptr32) return spmv_typed<double, uint32_t>(a, a->row_ptr32, (const double*)d_x, (double*)d_y, s);
-    return spmv_typed<double, uint64_t>(a, a->row_ptr, (const double*)d_x, (double*)d_y, s);
+    if (a->row_ptr32) return spmv_typed<double, uint32_t>(a, a->row_ptr32, (const double*)d_x, (double*)d_y, s, true);
+    return spmv_typed<double, uint64_t>(a, a->row_ptr, (const double*)d_x, (double*)d_y, s, true);
   }
-  if (a->row_ptr32) return spmv_typed<float, uint32_t>(a, a->row_ptr32, (const float*)d_x, (float*)d_y, s);
-  return spmv_typed<float, uint64_t>(a, a->row_ptr, (const float*)d_x, (float*)d_y, s);
+  if (a->row_ptr32) return spmv_typed<float, uint32_t>(a, a->row_ptr32, (const float*)d_x, (float*)d_y, s, true);
+  return spmv_typed<float, uint64_t>(a, a->row_ptr, (const float*)d_x, (float*)d_y, s, true);
 }
 
 template <class T>
@@ -492,6 +1306,24 @@ int spam_spmv_plan_info(const spam_csr* a, uint64_t* hot_columns, double* hot_co
   if (hot_columns) *hot_columns = p ? p->hot_k : 0;
   if (hot_cover) *hot_cover = p ? p->hot_cover : 0.0;
   if (tiles) *tiles = p ? p->ntiles : 0;
+  return SPAM_OK;
+}
+
+int spam_spmv_sliced_info(const spam_csr* a, int* active, uint64_t* long_rows, uint64_t* nnz_long, uint64_t* table_slots,
+                          uint64_t* lds_slots, double* cover_table, double* cover_single, double* ms_plain,
+                          double* ms_sliced) {
+  clear_error();
+  if (!a) return set_error(SPAM_E_INVALID, "matrix is NULL");
+  const SlicedPlan* q = a->spmv_plan ? a->spmv_plan->sliced : nullptr;
+  if (active) *active = q ? 1 : 0;
+  if (long_rows) *long_rows = q ? q->nl : 0;
+  if (nnz_long) *nnz_long = q ? q->nnz_long : 0;
+  if (table_slots) *table_slots = q ? q->S : 0;
+  if (lds_slots) *lds_slots = q ? q->L : 0;
+  if (cover_table) *cover_table = q ? q->cover_table : 0.0;
+  if (cover_single) *cover_single = q ? q->cover_single : 0.0;
+  if (ms_plain) *ms_plain = q ? q->ms_plain : 0.0;
+  if (ms_sliced) *ms_sliced = q ? q->ms_sliced : 0.0;
   return SPAM_OK;
 }
 

@@ -1,0 +1,162 @@
+"""The XCD-sliced SpMV path (spam_spmv.hip, second half) against the CPU oracle, through the C ABI.
+
+The path is chosen by the analysis only for vectors larger than one XCD's L2; here it is forced
+(SPAM_SPMV_SLICED=2) on small matrices with table budgets of a few KB, so that table columns, LDS-level columns,
+cold columns, long / residual rows, slab tiles with carries and the work stealing are all exercised.  The
+full-size cases (cfg2, cfg5) in test_spmv_gpu.py run whatever the analysis picks on the box.
+Tolerances as in test_spmv_gpu.py: 1e-10 relative f64, 1e-5 f32 against the f64-accumulated oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sparse_matrix_amd import synth
+from helpers import csr_np
+
+pytestmark = pytest.mark.gpu
+
+F64_RTOL = 1e-10
+F32_RTOL = 3e-5
+
+ENV_KEYS = ("SPAM_SPMV_SLICED", "SPAM_SPMV_SLICE_KB", "SPAM_SPMV_LDS_KB", "SPAM_SPMV_LONG", "SPAM_SPMV_SLICED_TPB",
+            "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS")
+
+
+@pytest.fixture
+def sliced_env():
+    saved = {k: os.environ.get(k) for k in ENV_KEYS}
+
+    def set_env(**kw):
+        for k in ENV_KEYS:
+            os.environ.pop(k, None)
+        os.environ["SPAM_SPMV_SLICED"] = "2"
+        for k, v in kw.items():
+            os.environ["SPAM_SPMV_" + k] = str(v)
+
+    yield set_env
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def _check(spam, oracle, off, idx, val, rows, cols, is_sorted, rtol, expect_active=True):
+    x = np.random.default_rng(11).uniform(0.5, 1.5, cols).astype(val.dtype)
+    A = spam.CsrMatrix(rows, cols, val, idx, off, is_sorted)
+    y = A.spmv(x)
+    info = A.device().spmv_plan_info()["sliced"]
+    if expect_active:
+        assert info["active"], info
+    ref = oracle.spmv((off, idx, val.astype(np.float64)), x.astype(np.float64))
+    nz = ref != 0
+    assert np.array_equal(y[~nz], np.zeros((~nz).sum(), dtype=y.dtype)), "rows without entries must give exactly 0"
+    if nz.any():
+        rel = np.abs(y[nz].astype(np.float64) - ref[nz]) / np.abs(ref[nz])
+        assert rel.max() <= rtol, f"max rel err {rel.max():.3e}"
+    y2 = A.spmv(x)
+    assert np.array_equal(y, y2), "the sliced path is deterministic (fixed tile and slab order)"
+    return info
+
+
+@pytest.mark.parametrize("cfg", [dict(SLICE_KB=4), dict(SLICE_KB=4, LDS_KB=1), dict(SLICE_KB=16, LDS_KB=4, LONG=1),
+                                 dict(SLICE_KB=2, LONG=40), dict(SLICE_KB=8, LDS_KB=8, SLICED_TPB=1024),
+                                 dict(SLICE_KB=8, SLICED_TPB=512), dict(SLICE_KB=4, SLICED_WGS=1),
+                                 dict(SLICE_KB=4, LDS_KB=2, SLICED_NPT=8)])
+@pytest.mark.parametrize("scale", [9, 14])
+def test_rmat_f64_forced(spam, oracle, sliced_env, cfg, scale):
+    sliced_env(**cfg)
+    m = synth.rmat(scale)
+    off, idx, val = csr_np(m)
+    info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL)
+    assert info["long_rows"] > 0 and info["table_slots_per_xcd"] > 0
+    if cfg.get("LDS_KB"):
+        assert info["lds_slots"] > 0
+
+
+def test_rmat_rect_cold_columns(spam, oracle, sliced_env):
+    """300k columns against 8 x 512 table slots: most columns are cold (gathered from x itself)."""
+    sliced_env(SLICE_KB=4, LDS_KB=1)
+    m = synth.rmat_rect(300_000, 4_800_000)
+    off, idx, val = csr_np(m)
+    info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL)
+    assert info["cover_table"] < 0.9
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, F32_RTOL), (torch.float64, F64_RTOL)])
+def test_powerlaw_long_rows_span_slab_tiles(spam, oracle, sliced_env, dtype, rtol):
+    """Rows of 30 000 entries: ~3750 per slab, so slab tiles carry row pieces into the fix-up."""
+    sliced_env(SLICE_KB=64, LDS_KB=8)
+    m = synth.powerlaw(40_000, heavy_every=1000, heavy_nnz=30_000, light_nnz=8, dtype=dtype)
+    off, idx, val = csr_np(m)
+    info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, rtol)
+    assert info["cover_table"] > 0.99  # 40 000 columns fit the eight tables
+
+
+def test_banded_and_identity(spam, oracle, sliced_env):
+    sliced_env(SLICE_KB=4, LONG=3)
+    m = synth.banded(10000, 5)
+    off, idx, val = csr_np(m)
+    _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL)
+    n = 5000
+    off = np.arange(n + 1, dtype=np.uint64)
+    _check(spam, oracle, off, np.arange(n, dtype=np.uint64), np.full(n, 1.25), n, n, True, F64_RTOL, expect_active=False)
+
+
+def test_all_rows_long_and_no_rows_long(spam, oracle, sliced_env):
+    m = synth.rmat(10)
+    off, idx, val = csr_np(m)
+    sliced_env(SLICE_KB=4, LONG=1)       # every non-empty row goes to the slabs, the residual is empty
+    info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL)
+    assert info["nnz_long"] == m.nnz
+    sliced_env(SLICE_KB=4, LONG=1 << 30)  # no row qualifies: the plain path runs
+    info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL, expect_active=False)
+    assert not info["active"]
+
+
+def test_randomized_shapes_forced(spam, oracle, sliced_env):
+    """60 random matrices (uniform / skewed / spiky row lengths, empty rows, shuffled rows, f64 / f32) with
+    varying table, LDS and long-row settings."""
+    rng = np.random.default_rng(23)
+    for case in range(60):
+        sliced_env(SLICE_KB=int(rng.choice([1, 2, 8, 32])), LDS_KB=int(rng.choice([0, 0, 1, 4])),
+                   LONG=int(rng.choice([1, 2, 5, 17])), SLICED_TPB=int(rng.choice([256, 512, 1024])),
+                   SLICED_NPT=int(rng.choice([8, 16])))
+        rows, cols = int(rng.integers(1, 30_001)), int(rng.integers(1, 50_001))
+        kind = case % 4
+        if kind == 0:
+            lens = rng.integers(0, 40, rows)
+        elif kind == 1:
+            lens = (rng.pareto(1.2, rows) * 3).astype(np.int64)
+        elif kind == 2:
+            lens = np.where(rng.random(rows) < 0.002, rng.integers(5000, 40_000, rows), rng.integers(0, 6, rows))
+        else:
+            lens = np.zeros(rows, dtype=np.int64)
+            lens[rng.integers(0, rows, max(1, rows // 50))] = rng.integers(1, 3000)
+        lens = np.minimum(lens, cols)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        if lens.sum() == 0:
+            continue
+        # skewed column choice so that table, LDS-level and cold columns all occur
+        w = rng.pareto(1.0, cols) + 1e-3
+        w /= w.sum()
+        idx = np.concatenate([rng.choice(cols, int(k), replace=False, p=w if k * 20 < cols else None) for k in lens if k])
+        is_sorted = bool(case % 3)
+        if is_sorted:
+            row_of = np.repeat(np.arange(rows), np.diff(off.astype(np.int64)))
+            idx = idx[np.lexsort((idx, row_of))]
+        dtype = np.float32 if case % 5 == 3 else np.float64
+        val = rng.uniform(0.5, 1.5, idx.size).astype(dtype)
+        _check(spam, oracle, off, idx.astype(np.uint64), val, rows, cols, is_sorted,
+               F64_RTOL if dtype == np.float64 else F32_RTOL, expect_active=False)
+
+
+def test_auto_mode_keeps_small_matrices_on_the_plain_path(spam, oracle, sliced_env):
+    sliced_env()
+    os.environ["SPAM_SPMV_SLICED"] = "1"
+    m = synth.rmat(12)
+    off, idx, val = csr_np(m)
+    info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL, expect_active=False)
+    assert not info["active"]

@@ -31,6 +31,8 @@ def main():
     res = {json.dumps(v): [] for v in variants}
     for r in range(rounds):
         for v in variants:
+            for k in [k for k in os.environ if k.startswith("SPAM_SPMV_")]:
+                del os.environ[k]
             for k, val in v.items():
                 os.environ[k] = str(val)
             dA.spmv_dev(x.data_ptr(), y.data_ptr())  # (re)build plan + warm
@@ -42,6 +44,8 @@ def main():
             e.record()
             torch.cuda.synchronize()
             res[json.dumps(v)].append(s.elapsed_time(e) / 10)
+            if r == 0:
+                print(json.dumps(v), "plan:", dA.spmv_plan_info(), flush=True)
     for k, ts in res.items():
         med = float(np.median(ts))
         print(f"{k}: median {med:.4f} ms  min {min(ts):.4f}  -> {nbytes / med / 1e6:.0f} GB/s ({nbytes / med / 1e6 / 80:.1f}% of 8 TB/s)")
