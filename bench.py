@@ -167,15 +167,33 @@ def main():
                          "kernel": "spmv_tile_kernel(+fixup)", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes": nbytes},
         })
-        # what the gather allows on this chip (tools/gather_bench.hip): 245 G gathers/s when they hit L2, 52 G/s when
-        # they miss (a 128-byte line crosses the fabric per miss); the hot table makes `hot_cover` of them hit
+        # what the gather allows on this chip (tools/gather_bench.hip, tools/xcd_gather_bench.hip): 245 G gathers/s when
+        # they hit the XCD's L2 (one request per lane: the L2's request rate), 52 G/s when they miss (a 128-byte line
+        # crosses the fabric per miss).  Plain path: one 3 MB hot table makes `hot_cover` of them hit.  XCD-sliced path:
+        # eight per-XCD tables make `cover_table` of the long rows' gathers hit (230 G/s measured with every workgroup on
+        # its own XCD's slice), the rest and the short rows' misses pay the fabric rate.
         info = dA.spmv_plan_info()
-        hits = info["hot_cover"] * A.nnz if info["hot_columns"] else 0.0
-        model_ms = max(nbytes / 5.8e12, hits / 245e9 + (A.nnz - hits) / 52e9) * 1e3
-        out["roofline"]["gather_model"] = {"hot_columns": info["hot_columns"], "hot_cover": round(info["hot_cover"], 4),
-                                           "l2_hit_gathers_per_s": 245e9, "l2_miss_gathers_per_s": 52e9,
-                                           "bound_ms": round(model_ms, 4), "frac_of_bound": round(model_ms / kern_ms, 4),
-                                           "source": "profiles/r01_gather_microbench.txt"}
+        sl = info["sliced"]
+        if sl["active"]:
+            hits = sl["cover_table"] * sl["nnz_long"]
+            model_ms = max(nbytes / 5.8e12, hits / 230e9 + (sl["nnz_long"] - hits) / 52e9) * 1e3
+            out["roofline"]["kernel"] = ("XCD-sliced SpMV: sliced_build_tables + spmv_short_rows + spmv_sliced_pipe_kernel "
+                                         "+ sliced_fixup + sliced_reduce (whole step)")
+            out["roofline"]["gather_model"] = {"mode": "xcd_sliced", "l2_hit_gathers_per_s": 230e9, "l2_miss_gathers_per_s": 52e9,
+                                               "bound_ms": round(model_ms, 4), "frac_of_bound": round(model_ms / kern_ms, 4),
+                                               "source": "profiles/r01_xcd_gather_microbench.txt"}
+            out["config"]["spmv_plan"] = {"mode": "xcd_sliced", "rows_in_slabs": sl["long_rows"], "nnz_in_slabs": sl["nnz_long"],
+                                          "table_slots_per_xcd": sl["table_slots_per_xcd"], "hottest_slots_l1_lds": sl["lds_slots"],
+                                          "cover_8_tables": round(sl["cover_table"], 4), "cover_1_table": round(sl["cover_single"], 4),
+                                          "autotune_ms_plain": round(sl["ms_plain"], 4), "autotune_ms_sliced": round(sl["ms_sliced"], 4)}
+        else:
+            hits = info["hot_cover"] * A.nnz if info["hot_columns"] else 0.0
+            model_ms = max(nbytes / 5.8e12, hits / 245e9 + (A.nnz - hits) / 52e9) * 1e3
+            out["roofline"]["gather_model"] = {"mode": "plain", "hot_columns": info["hot_columns"], "hot_cover": round(info["hot_cover"], 4),
+                                               "l2_hit_gathers_per_s": 245e9, "l2_miss_gathers_per_s": 52e9,
+                                               "bound_ms": round(model_ms, 4), "frac_of_bound": round(model_ms / kern_ms, 4),
+                                               "source": "profiles/r01_gather_microbench.txt"}
+            out["config"]["spmv_plan"] = {"mode": "plain", "hot_columns": info["hot_columns"]}
         # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc run (tools/prof_bench.sh), never from this process
         pmc = os.path.join(ROOT, "profiles", "spmv_pmc_latest.json")
         if os.path.exists(pmc):

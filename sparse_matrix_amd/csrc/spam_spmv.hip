@@ -107,6 +107,10 @@ struct Vec4<float> {
   static constexpr int N = 4;
 };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Explicit global address space: pointers that a kernel reads from a descriptor in memory are generic to the
+// compiler (flat_load, which also occupies the LDS counter and is waited for one at a time); the tile body takes
+// global pointers so both kernels get global_load / global_store.
+#define SPAM_GLB __attribute__((address_space(1)))
 
 __device__ __forceinline__ int pad_idx(int i) { return i + (i >> 5); }
 
@@ -114,6 +118,30 @@ template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// Sum over the wavefront through DPP moves (no LDS crossbar traffic, ~10x less latency than six ds_bpermute
+// rounds for a double); the total arrives in lane 63 only.  Lanes without a source lane add 0.
+template <int CTRL, int ROW_MASK, class T>
+__device__ __forceinline__ T dpp_shift(T v) {
+  if constexpr (sizeof(T) == 8) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(T, ((long long)hi << 32) | (long long)(unsigned)lo);
+  } else {
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+  }
+}
+template <class T>
+__device__ __forceinline__ T wave_sum_lane63(T v) {
+  v += dpp_shift<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_shift<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_shift<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_shift<0x118, 0xF>(v);  // row_shr:8  -> lane 15 of every 16-lane row holds the row's sum
+  v += dpp_shift<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_shift<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds everything
   return v;
 }
 
@@ -155,92 +183,96 @@ struct TileSmem {
 // all tiles: [0] stream + gather + products, [1] barrier, [2] short rows, [3] barrier + long rows, [4] dequeue, [5] tiles
 __device__ unsigned long long g_spmv_prof[8];
 
-// One tile of TPB*NPT entries: products into LDS, then per-row sums.  `tile_idx` is the tile's number inside the
-// (row_ptr, col, val) arrays it is given; G maps a stored column code to the x value.
-// Phase 2 never waits on global memory: the tile's slice of row_ptr (rows fo[t] .. fo[t+1]) is loaded while the
-// gathers are in flight and staged in LDS as tile-local offsets; tiles with more than RCAP-1 rows (runs of empty or
-// one-entry rows) take further passes.
-template <class T, class OffT, int TPB, int NPT, bool NT, class G, int PROF = 0>
-__device__ __forceinline__ void spmv_tile_body(TileSmem<T, TPB, NPT>& sm, const OffT* __restrict__ row_ptr,
-                                               const uint32_t* __restrict__ col, const T* __restrict__ val, const G& gx,
-                                               T* __restrict__ y, const uint32_t* __restrict__ fo, T* __restrict__ carry,
-                                               uint64_t nnz, uint32_t tile_idx) {
+// Everything one thread holds of a FULL tile between issuing its loads and writing the products to LDS.
+template <class T, class OffT, int TPB, int NPT>
+struct TileRegs {
+  using VT = typename Vec4<T>::type;
+  static constexpr int VN = Vec4<T>::N;     // values per 16-byte load
+  static constexpr int NV = NPT / 4;        // 16-byte index loads per thread
+  static constexpr int RK = TileSmem<T, TPB, NPT>::RK;
+  VT v[NV][4 / VN];
+  T xv[NV][4];
+  OffT rraw[RK];
+  uint32_t f0, f1;
+};
+
+// Full tile, step 1: issue every global load of the tile — ja / a stream, the x gathers, and behind them the tile's
+// slice of row_ptr (unconditional loads with a clamped index: they go out back to back; the compiler barriers keep
+// them from being hoisted in front of the stream and waited for one at a time).  Nothing is waited for beyond what
+// the gather addresses need.
+template <class T, class OffT, int TPB, int NPT, bool NT, class G>
+__device__ __forceinline__ void tile_issue(TileRegs<T, OffT, TPB, NPT>& r, const OffT SPAM_GLB* __restrict__ row_ptr,
+                                           const uint32_t SPAM_GLB* __restrict__ col, const T SPAM_GLB* __restrict__ val,
+                                           const G& gx, const uint32_t SPAM_GLB* __restrict__ fo, uint32_t tile_idx) {
+  using R = TileRegs<T, OffT, TPB, NPT>;
+  using VT = typename R::VT;
+  constexpr int VN = R::VN, NV = R::NV, RK = R::RK, TILE = TPB * NPT;
+  const int tid = threadIdx.x;
+  const uint64_t base = (uint64_t)tile_idx * TILE;
+  r.f0 = fo[tile_idx], r.f1 = fo[tile_idx + 1];
+  u32x4 c[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const uint64_t q = base + (uint64_t)(i * TPB + tid) * 4;
+    if (NT) {
+      c[i] = __builtin_nontemporal_load((const SPAM_GLB u32x4*)(col + q));
+#pragma unroll
+      for (int j = 0; j < 4 / VN; ++j) r.v[i][j] = __builtin_nontemporal_load((const SPAM_GLB VT*)(val + q) + j);
+    } else {
+      c[i] = *(const SPAM_GLB u32x4*)(col + q);
+#pragma unroll
+      for (int j = 0; j < 4 / VN; ++j) r.v[i][j] = *((const SPAM_GLB VT*)(val + q) + j);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.xv[i][j] = gx(c[i][j]);
+  }
+  asm volatile("" ::: "memory");
+  const uint32_t nv0 = r.f1 - r.f0 + 1;
+#pragma unroll
+  for (int k = 0; k < RK; ++k) {
+    const uint32_t i = (uint32_t)(k * TPB + tid);
+    r.rraw[k] = row_ptr[r.f0 + (i < nv0 ? i : nv0 - 1)];
+  }
+  asm volatile("" ::: "memory");
+}
+
+// Full tile, step 2: products and the tile-local row offsets into LDS (waits for the loads of tile_issue).
+template <class T, class OffT, int TPB, int NPT>
+__device__ __forceinline__ void tile_finish(const TileRegs<T, OffT, TPB, NPT>& r, TileSmem<T, TPB, NPT>& sm,
+                                            uint32_t tile_idx) {
+  using R = TileRegs<T, OffT, TPB, NPT>;
+  constexpr int VN = R::VN, NV = R::NV, RK = R::RK, TILE = TPB * NPT;
+  const int tid = threadIdx.x;
+  const uint64_t base = (uint64_t)tile_idx * TILE, end = base + TILE;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = (i * TPB + tid) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm.prod[pad_idx(q + j)] = r.v[i][j / VN][j % VN] * r.xv[i][j];
+  }
+#pragma unroll
+  for (int k = 0; k < RK; ++k) {
+    const uint64_t rv = (uint64_t)r.rraw[k];
+    sm.rp[k * TPB + tid] = (uint16_t)((rv < end ? rv : end) - base);
+  }
+}
+
+// Step 3 (after a barrier): per-row sums of the tile's `cnt` products, everything from LDS.  sm.rp holds the first
+// min(nv, RCAP) tile-local offsets of rows f0 .. f1; tiles with more rows (runs of empty or one-entry rows) restage.
+// sm.n_long must be 0 on entry.
+template <class T, class OffT, int TPB, int NPT, int PROF = 0>
+__device__ __forceinline__ void tile_phase2(TileSmem<T, TPB, NPT>& sm, const OffT SPAM_GLB* __restrict__ row_ptr,
+                                            T SPAM_GLB* __restrict__ y, T SPAM_GLB* __restrict__ carry, uint32_t f0,
+                                            uint32_t f1, uint64_t base, uint64_t end, uint32_t tile_idx, long long* pt3) {
   using SM = TileSmem<T, TPB, NPT>;
-  constexpr int TILE = TPB * NPT;
-  constexpr int RK = SM::RK, RCAP = SM::RCAP;
+  constexpr int RCAP = SM::RCAP;
   constexpr uint32_t CARRY = 0xFFFFFFFFu;
   T* prod = sm.prod;
   uint32_t* long_list = sm.long_list;
-
   const int tid = threadIdx.x;
-  const uint64_t base = (uint64_t)tile_idx * TILE;
-  const uint32_t cnt = (uint32_t)((nnz - base) < (uint64_t)TILE ? (nnz - base) : (uint64_t)TILE);
-  const uint64_t end = base + cnt;
-  if (tid == 0) sm.n_long = 0;
-  long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
-  if (PROF) pt0 = clock64();
-  const uint32_t f0 = fo[tile_idx], f1 = fo[tile_idx + 1];
-  uint32_t rpv[RK];
-
-  // ---- phase 1: stream ja / a, (row_ptr slice), gather x, products -> LDS ----------------------------
-  if (cnt == TILE) {
-    using VT = typename Vec4<T>::type;
-    constexpr int VN = Vec4<T>::N;     // values per 16-byte load
-    constexpr int NV = NPT / 4;        // 16-byte index loads per thread
-    u32x4 c[NV];
-    VT v[NV][4 / VN];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const uint64_t q = base + (uint64_t)(i * TPB + tid) * 4;
-      if (NT) {
-        c[i] = __builtin_nontemporal_load((const u32x4*)(col + q));
-#pragma unroll
-        for (int j = 0; j < 4 / VN; ++j) v[i][j] = __builtin_nontemporal_load((const VT*)(val + q) + j);
-      } else {
-        c[i] = *(const u32x4*)(col + q);
-#pragma unroll
-        for (int j = 0; j < 4 / VN; ++j) v[i][j] = *((const VT*)(val + q) + j);
-      }
-    }
-    const uint32_t nv0 = f1 - f0 + 1;
-#pragma unroll
-    for (int k = 0; k < RK; ++k) {
-      const uint32_t i = (uint32_t)(k * TPB + tid);
-      uint64_t rv = end;
-      if (i < nv0) rv = (uint64_t)row_ptr[f0 + i];
-      rpv[k] = (uint32_t)((rv < end ? rv : end) - base);
-    }
-    T xv[NV][4];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xv[i][j] = gx(c[i][j]);
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int q = (i * TPB + tid) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) prod[pad_idx(q + j)] = v[i][j / VN][j % VN] * xv[i][j];
-    }
-  } else {
-    const uint32_t nv0 = f1 - f0 + 1;
-#pragma unroll
-    for (int k = 0; k < RK; ++k) {
-      const uint32_t i = (uint32_t)(k * TPB + tid);
-      uint64_t rv = end;
-      if (i < nv0) rv = (uint64_t)row_ptr[f0 + i];
-      rpv[k] = (uint32_t)((rv < end ? rv : end) - base);
-    }
-    for (uint32_t q = tid; q < cnt; q += TPB) prod[pad_idx(q)] = val[base + q] * gx(col[base + q]);
-  }
-#pragma unroll
-  for (int k = 0; k < RK; ++k) sm.rp[k * TPB + tid] = (uint16_t)rpv[k];
-  if (PROF == 2) return;  // experiment: phase 1 only (wrong results)
-  if (PROF) pt1 = clock64();
-  __syncthreads();
-  if (PROF) pt2 = clock64();
-
-  // ---- phase 2: per-row sums, everything from LDS -------------------------------------------------------
   const uint32_t nv = f1 - f0 + 1;  // row_ptr values of this tile: rows f0 .. f1 - 1 plus the closing offset
   const int lane = tid & 63, wave = tid >> 6;
   uint32_t row0 = 0;                // rows finished in earlier passes
@@ -253,17 +285,24 @@ __device__ __forceinline__ void spmv_tile_body(TileSmem<T, TPB, NPT>& sm, const 
       const uint32_t s = sm.rp[i], e = sm.rp[i + 1];
       const uint32_t len = e - s;
       if (len <= SHORT_ROW) {
+        // left to right (the oracle's order); four LDS reads are issued together so their latencies overlap
         T acc = T(0);
-        if (len) {
-          acc = prod[pad_idx((int)s)];
-          for (uint32_t k = 1; k < len; ++k) acc += prod[pad_idx((int)(s + k))];
+        uint32_t k = 0;
+        for (; k + 4 <= len; k += 4) {
+          const T p0 = prod[pad_idx((int)(s + k))], p1 = prod[pad_idx((int)(s + k + 1))];
+          const T p2 = prod[pad_idx((int)(s + k + 2))], p3 = prod[pad_idx((int)(s + k + 3))];
+          acc = k ? acc + p0 : p0;
+          acc += p1;
+          acc += p2;
+          acc += p3;
         }
+        for (; k < len; ++k) acc = k ? acc + prod[pad_idx((int)(s + k))] : prod[pad_idx((int)(s + k))];
         y[f0 + row0 + i] = acc;
       } else {
         long_list[atomicAdd(&sm.n_long, 1u)] = i;
       }
     }
-    if (PROF && row0 == 0) pt3 = clock64();
+    if (PROF && row0 == 0) *pt3 = clock64();
     __syncthreads();
     const uint32_t nl = sm.n_long;
     for (uint32_t j = wave; j < nl; j += TPB / 64) {
@@ -276,9 +315,15 @@ __device__ __forceinline__ void spmv_tile_body(TileSmem<T, TPB, NPT>& sm, const 
         e = sm.rp[i + 1];
       }
       T acc = T(0);
-      for (int p = (int)s + lane, pe = (int)e; p < pe; p += 64) acc += prod[pad_idx(p)];
-      acc = wave_sum(acc);
-      if (lane == 0) {
+      int p = (int)s + lane;
+      const int pe = (int)e;
+      for (; p + 192 < pe; p += 256) {
+        const T p0 = prod[pad_idx(p)], p1 = prod[pad_idx(p + 64)], p2 = prod[pad_idx(p + 128)], p3 = prod[pad_idx(p + 192)];
+        acc += (p0 + p1) + (p2 + p3);
+      }
+      for (; p < pe; p += 64) acc += prod[pad_idx(p)];
+      acc = wave_sum_lane63(acc);
+      if (lane == 63) {
         if (i == CARRY)
           carry[tile_idx] = acc;
         else
@@ -296,6 +341,50 @@ __device__ __forceinline__ void spmv_tile_body(TileSmem<T, TPB, NPT>& sm, const 
     }
     __syncthreads();
   }
+}
+
+// One tile of TPB*NPT entries start to end: products into LDS, then per-row sums.  `tile_idx` is the tile's number
+// inside the (row_ptr, col, val) arrays it is given; G maps a stored column code to the x value.
+// Phase 2 never waits on global memory: the tile's slice of row_ptr (rows fo[t] .. fo[t+1]) is loaded while the
+// gathers are in flight and staged in LDS as tile-local offsets.
+template <class T, class OffT, int TPB, int NPT, bool NT, class G, int PROF = 0>
+__device__ __forceinline__ void spmv_tile_body(TileSmem<T, TPB, NPT>& sm, const OffT SPAM_GLB* __restrict__ row_ptr,
+                                               const uint32_t SPAM_GLB* __restrict__ col,
+                                               const T SPAM_GLB* __restrict__ val, const G& gx, T SPAM_GLB* __restrict__ y,
+                                               const uint32_t SPAM_GLB* __restrict__ fo, T SPAM_GLB* __restrict__ carry,
+                                               uint64_t nnz, uint32_t tile_idx) {
+  using SM = TileSmem<T, TPB, NPT>;
+  constexpr int TILE = TPB * NPT;
+  constexpr int RK = SM::RK;
+  const int tid = threadIdx.x;
+  const uint64_t base = (uint64_t)tile_idx * TILE;
+  const uint32_t cnt = (uint32_t)((nnz - base) < (uint64_t)TILE ? (nnz - base) : (uint64_t)TILE);
+  const uint64_t end = base + cnt;
+  if (tid == 0) sm.n_long = 0;
+  long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
+  if (PROF) pt0 = clock64();
+  uint32_t f0, f1;
+  if (cnt == TILE) {
+    TileRegs<T, OffT, TPB, NPT> r;
+    tile_issue<T, OffT, TPB, NPT, NT>(r, row_ptr, col, val, gx, fo, tile_idx);
+    tile_finish<T, OffT, TPB, NPT>(r, sm, tile_idx);
+    f0 = r.f0, f1 = r.f1;
+  } else {
+    f0 = fo[tile_idx], f1 = fo[tile_idx + 1];
+    const uint32_t nv0 = f1 - f0 + 1;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+      const uint32_t i = (uint32_t)(k * TPB + tid);
+      const uint64_t rv = (uint64_t)row_ptr[f0 + (i < nv0 ? i : nv0 - 1)];
+      sm.rp[k * TPB + tid] = (uint16_t)((rv < end ? rv : end) - base);
+    }
+    for (uint32_t q = tid; q < cnt; q += TPB) sm.prod[pad_idx(q)] = val[base + q] * gx(col[base + q]);
+  }
+  if (PROF == 2) return;  // experiment: phase 1 only (wrong results)
+  if (PROF) pt1 = clock64();
+  __syncthreads();
+  if (PROF) pt2 = clock64();
+  tile_phase2<T, OffT, TPB, NPT, PROF>(sm, row_ptr, y, carry, f0, f1, base, end, tile_idx, &pt3);
   if (PROF && tid == 0) {
     const long long pt4 = clock64();
     atomicAdd(&g_spmv_prof[0], (unsigned long long)(pt1 - pt0));
@@ -315,7 +404,9 @@ __global__ __launch_bounds__(SPMV_TPB) void spmv_tile_kernel(const OffT* __restr
                                                             uint64_t nnz) {
   __shared__ TileSmem<T, SPMV_TPB, NPT> sm;
   const GatherPlain<T, HOT> gx{x, xh};
-  spmv_tile_body<T, OffT, SPMV_TPB, NPT, NT>(sm, row_ptr, col, val, gx, y, fo, carry, nnz, blockIdx.x);
+  spmv_tile_body<T, OffT, SPMV_TPB, NPT, NT>(sm, (const OffT SPAM_GLB*)row_ptr, (const uint32_t SPAM_GLB*)col,
+                                             (const T SPAM_GLB*)val, gx, (T SPAM_GLB*)y, (const uint32_t SPAM_GLB*)fo,
+                                             (T SPAM_GLB*)carry, nnz, blockIdx.x);
 }
 
 // Fold the pieces of rows that span several tiles, in tile order.
@@ -495,7 +586,8 @@ static int bisect_threshold(const uint32_t* cnt, uint32_t cols, uint64_t kmax, h
 // =====================================================================================================
 // XCD-sliced SpMV
 // =====================================================================================================
-constexpr int NSLAB = 8;                      // one slab per XCD of MI355X
+constexpr int NSLAB = 8;                      // one table slab per XCD of MI355X
+constexpr int NPART = NSLAB + 1;              // + the cold part: entries whose column is in no table (gathered from x)
 constexpr uint32_t NO_DEST = 0xFFFFFFFFu;
 constexpr int HEAD_STRIDE = 64;               // u32 words between two queue heads: one 256-byte block each, so the
                                               // eight XCDs' dequeue atomics do not serialise on one line
@@ -503,9 +595,9 @@ constexpr int HEAD_STRIDE = 64;               // u32 words between two queue hea
 template <class T>
 struct SlabDesc {
   const uint32_t* row_ptr;  // u32[nl + 1]: entry offsets of the compact long rows inside this slab
-  const uint32_t* col;      // column codes: < S table slot, otherwise S + column
+  const uint32_t* col;      // table slot inside the slab (the column index itself in the cold part)
   const T* val;
-  const T* xh;              // this slab's packed x table, S slots
+  const T* xh;              // this slab's packed x table, S slots (unused in the cold part: x itself)
   T* y;                     // partial sums over the long rows, T[nl]
   const uint32_t* fo;       // first_owned of this slab's tiles
   T* carry;
@@ -514,7 +606,11 @@ struct SlabDesc {
 
 struct SlicedPlan {
   int mode_built = 0;           // the configuration key this plan was built for
-  uint32_t S = 0, L = 0;        // table slots per slab; the first L of them are also kept in LDS
+  uint32_t S = 0, L = 0;        // table slots per slab; the first L hold the most referenced columns, contiguous (they
+                                // stay in the CU's 32 KB L1; with use_lds every workgroup copies them to LDS instead)
+  bool use_lds = false;
+  bool pipelined = true;        // software-pipelined persistent kernel (SPAM_SPMV_PIPE=0: the plain loop)
+  uint32_t ns = 0;              // non-empty short rows
   uint32_t nl = 0;              // long rows
   uint32_t long_min = 0;        // rows with >= long_min entries are long
   int tpb = 256, npt = 16;
@@ -525,21 +621,22 @@ struct SlicedPlan {
   uint32_t* dest = nullptr;       // u32[cols]: flat table index of a table column, NO_DEST otherwise
   void* xh = nullptr;             // T[NSLAB * S]
   uint32_t* long_rows = nullptr;  // u32[nl]
-  uint32_t* srow_ptr = nullptr;   // u32[NSLAB][nl + 1]
+  uint32_t* short_rows = nullptr; // u32[ns]
+  uint32_t* srow_ptr = nullptr;   // u32[NPART][nl + 1]
   uint32_t* scol = nullptr;
   void* sval = nullptr;
   uint32_t* sfo = nullptr;
   void* scarry = nullptr;
-  void* partial = nullptr;        // T[NSLAB][nl]
-  void* descs = nullptr;          // SlabDesc<T>[NSLAB] on the device
-  uint32_t* heads = nullptr;      // u32[NSLAB] tile queue heads
-  spam_csr* residual = nullptr;   // the short rows (long rows empty), same shape as the matrix
+  void* partial = nullptr;        // T[NPART][nl]
+  void* descs = nullptr;          // SlabDesc<T>[NPART] on the device
+  uint32_t* heads = nullptr;      // tile queue heads, HEAD_STRIDE words apart
+  spam_csr* residual = nullptr;   // the non-empty short rows, compacted (row_ptr32 has ns + 1 entries)
   float ms_plain = 0, ms_sliced = 0;
 };
 
 static void sliced_plan_free(SlicedPlan* q) {
   if (!q) return;
-  void* ptrs[] = {q->dest, q->xh, q->long_rows, q->srow_ptr, q->scol, q->sval, q->sfo, q->scarry, q->partial, q->descs, q->heads};
+  void* ptrs[] = {q->dest, q->xh, q->long_rows, q->short_rows, q->srow_ptr, q->scol, q->sval, q->sfo, q->scarry, q->partial, q->descs, q->heads};
   for (void* p : ptrs)
     if (p) dev_free(p);
   if (q->residual) {
@@ -559,23 +656,18 @@ __device__ __forceinline__ uint32_t xcc_id() {
   return v;
 }
 
-// MODE 0: table slots from the slab table (or LDS), cold columns by a non-temporal load from x.
-// MODE 1 (experiment, wrong results): cold codes wrapped into the table.  MODE 2: one load, per-lane base select.
-template <class T, int MODE = 0>
+// One tile gathers either from a slab table (the first L slots from LDS when the workgroup holds them) or, in the
+// cold part, from x itself with non-temporal loads; the choice is uniform per tile, so no lane diverges.
+template <class T>
 struct GatherSliced {
-  const T* __restrict__ x;
-  const T* __restrict__ xh;
+  const T SPAM_GLB* __restrict__ base;
   const T* lds;
-  uint32_t S, L;
+  uint32_t L;
+  bool cold;
   __device__ __forceinline__ T operator()(uint32_t c) const {
-    if (MODE == 1) return xh[c < S ? c : c % S];
-    if (MODE == 2) {
-      const T* b = c < S ? xh + c : x + (c - S);
-      return *b;
-    }
+    if (cold) return __builtin_nontemporal_load(base + c);
     if (c < L) return lds[c];
-    if (c < S) return xh[c];
-    return __builtin_nontemporal_load(x + (c - S));
+    return base[c];
   }
 };
 
@@ -593,11 +685,12 @@ __global__ __launch_bounds__(TPB) void spmv_sliced_kernel(const SlabDesc<T>* __r
     const T* src = descs[home].xh;
     for (uint32_t j = threadIdx.x; j < L; j += TPB) tab[j] = src[j];
   }
-  for (uint32_t d = 0; d < NSLAB; ++d) {
-    const uint32_t k = (home + d) & (NSLAB - 1);
+  // own slab first, then the cold part (any XCD), then whatever the other XCDs have left
+  for (uint32_t d = 0; d < NPART; ++d) {
+    const uint32_t k = d == 0 ? home : (d == 1 ? (uint32_t)NSLAB : ((home + d - 1) & (NSLAB - 1)));
     const SlabDesc<T> sd = descs[k];
-    constexpr int GM = PROF >= 3 ? PROF - 2 : 0;
-    const GatherSliced<T, GM> gx{x, sd.xh, tab, S, (LDS && d == 0) ? L : 0u};
+    const bool cold = k == NSLAB;
+    const GatherSliced<T> gx{(const T SPAM_GLB*)(cold ? x : sd.xh), tab, (LDS && d == 0) ? L : 0u, cold};
     uint32_t* head = heads + k * HEAD_STRIDE;
     if (threadIdx.x == 0) s_t = atomicAdd(head, 1u);
     __syncthreads();
@@ -606,8 +699,9 @@ __global__ __launch_bounds__(TPB) void spmv_sliced_kernel(const SlabDesc<T>* __r
     while (t < sd.ntiles) {
       uint32_t nxt = 0;
       if (threadIdx.x == 0) nxt = atomicAdd(head, 1u);  // the next ticket travels while this tile is processed
-      spmv_tile_body<T, uint32_t, TPB, NPT, true, GatherSliced<T, GM>, (PROF >= 3 ? 0 : PROF)>(sm, sd.row_ptr, sd.col, sd.val, gx, sd.y, sd.fo, sd.carry,
-                                                                          sd.nnz, t);
+      spmv_tile_body<T, uint32_t, TPB, NPT, true, GatherSliced<T>, PROF>(
+          sm, (const uint32_t SPAM_GLB*)sd.row_ptr, (const uint32_t SPAM_GLB*)sd.col, (const T SPAM_GLB*)sd.val, gx,
+          (T SPAM_GLB*)sd.y, (const uint32_t SPAM_GLB*)sd.fo, (T SPAM_GLB*)sd.carry, sd.nnz, t);
       long long q0 = 0;
       if (PROF) q0 = clock64();
       if (threadIdx.x == 0) s_t = nxt;
@@ -615,6 +709,75 @@ __global__ __launch_bounds__(TPB) void spmv_sliced_kernel(const SlabDesc<T>* __r
       t = s_t;
       __syncthreads();
       if (PROF && threadIdx.x == 0) atomicAdd(&g_spmv_prof[4], (unsigned long long)(clock64() - q0));
+    }
+  }
+}
+
+// The same work, software-pipelined: while a workgroup sums the rows of tile i out of LDS, the loads of its next
+// tile (stream, gathers, row_ptr slice) are already in flight, so the L2 keeps receiving gathers from every resident
+// workgroup all the time (with the unpipelined loop a workgroup's phase 2 and its three dependent load latencies
+// per tile leave the L2 request queues a third empty: 175 instead of 230 G gathers/s).  Tickets are drawn two ahead.
+template <class T, int TPB, int NPT, bool LDS, int PROF = 0>
+__global__ __launch_bounds__(TPB) void spmv_sliced_pipe_kernel(const SlabDesc<T>* __restrict__ descs, const T* __restrict__ x,
+                                                              uint32_t S, uint32_t L, uint32_t* __restrict__ heads) {
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  __shared__ TileSmem<T, TPB, NPT> sm;
+  __shared__ uint32_t s_t[2];
+  constexpr uint32_t TILE = TPB * NPT;
+  const uint32_t home = xcc_id() & (NSLAB - 1);
+  T* tab = reinterpret_cast<T*>(dyn_lds);
+  if (LDS) {
+    const T* src = descs[home].xh;
+    for (uint32_t j = threadIdx.x; j < L; j += TPB) tab[j] = src[j];
+  }
+  TileRegs<T, uint32_t, TPB, NPT> r;
+  for (uint32_t d = 0; d < NPART; ++d) {
+    const uint32_t k = d == 0 ? home : (d == 1 ? (uint32_t)NSLAB : ((home + d - 1) & (NSLAB - 1)));
+    const SlabDesc<T> sd = descs[k];
+    const bool cold = k == NSLAB;
+    const GatherSliced<T> gx{(const T SPAM_GLB*)(cold ? x : sd.xh), tab, (LDS && d == 0) ? L : 0u, cold};
+    const uint32_t SPAM_GLB* row_ptr = (const uint32_t SPAM_GLB*)sd.row_ptr;
+    const uint32_t SPAM_GLB* col = (const uint32_t SPAM_GLB*)sd.col;
+    const T SPAM_GLB* val = (const T SPAM_GLB*)sd.val;
+    const uint32_t SPAM_GLB* fo = (const uint32_t SPAM_GLB*)sd.fo;
+    T SPAM_GLB* y = (T SPAM_GLB*)sd.y;
+    T SPAM_GLB* carry = (T SPAM_GLB*)sd.carry;
+    const uint32_t nfull = sd.nnz / TILE;  // tiles [0, nfull) are full, a last shorter one may follow
+    uint32_t* head = heads + k * HEAD_STRIDE;
+    if (threadIdx.x == 0) {
+      s_t[0] = atomicAdd(head, 1u);
+      s_t[1] = atomicAdd(head, 1u);
+    }
+    __syncthreads();
+    uint32_t t_cur = s_t[0], t_next = s_t[1];
+    __syncthreads();
+    bool loaded = t_cur < nfull;
+    if (loaded) tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, gx, fo, t_cur);
+    while (t_cur < sd.ntiles) {
+      uint32_t t_nn = 0;
+      if (threadIdx.x == 0) {
+        t_nn = atomicAdd(head, 1u);
+        sm.n_long = 0;
+      }
+      if (loaded) {
+        tile_finish<T, uint32_t, TPB, NPT>(r, sm, t_cur);
+        const uint32_t f0 = r.f0, f1 = r.f1;
+        __syncthreads();
+        loaded = t_next < nfull;
+        if (loaded) tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, gx, fo, t_next);
+        const uint64_t base = (uint64_t)t_cur * TILE;
+        if (PROF != 2)  // 2: experiment, loads and products only (wrong results)
+          tile_phase2<T, uint32_t, TPB, NPT>(sm, row_ptr, y, carry, f0, f1, base, base + TILE, t_cur, nullptr);
+      } else {
+        spmv_tile_body<T, uint32_t, TPB, NPT, true>(sm, row_ptr, col, val, gx, y, fo, carry, sd.nnz, t_cur);
+        loaded = t_next < nfull;
+        if (loaded) tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, gx, fo, t_next);
+      }
+      if (threadIdx.x == 0) s_t[0] = t_nn;
+      __syncthreads();
+      t_cur = t_next;
+      t_next = s_t[0];
+      __syncthreads();
     }
   }
 }
@@ -634,7 +797,7 @@ __global__ void sliced_fixup_kernel(const SlabDesc<T>* __restrict__ descs, uint3
   sd.y[f - 1] = acc;
 }
 
-// y[long row] = sum of the slab partials, in slab order (deterministic)
+// y[long row] = sum of the 8 slab partials and the cold partial, in that order (deterministic)
 template <class T>
 __global__ void sliced_reduce_kernel(const T* __restrict__ partial, const uint32_t* __restrict__ long_rows, uint32_t nl,
                                      T* __restrict__ y) {
@@ -642,26 +805,30 @@ __global__ void sliced_reduce_kernel(const T* __restrict__ partial, const uint32
   if (i >= nl) return;
   T acc = partial[i];
 #pragma unroll
-  for (int k = 1; k < NSLAB; ++k) acc += partial[(uint64_t)k * nl + i];
+  for (int k = 1; k < NPART; ++k) acc += partial[(uint64_t)k * nl + i];
   y[long_rows[i]] = acc;
 }
 
-// The rows left in the residual CSR (fewer than long_min entries): one lane per row, summed left to right — the
-// oracle's order, so these rows are bit-identical to it.  Rows that went to the slabs are empty here and get a 0
-// that the reduce kernel overwrites later on the same stream.
+// The non-empty rows of fewer than long_min entries (compacted): one lane per row, summed left to right — the
+// oracle's order, so these rows are bit-identical to it.  The first two entries are loaded together (the kernel is
+// latency-bound: every entry is a chain of two dependent loads).  y was zero-filled before (empty rows).
 template <class T, int HOT>
 __global__ __launch_bounds__(256) void spmv_short_rows_kernel(const uint32_t* __restrict__ res_ptr,
                                                               const uint32_t* __restrict__ col, const T* __restrict__ val,
                                                               const T* __restrict__ x, const T* __restrict__ xh,
-                                                              uint32_t rows, T* __restrict__ y) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  const uint32_t s = res_ptr[r], e = res_ptr[r + 1];
-  T acc = T(0);
-  if (s < e) {
-    acc = val[s] * gather_x<T, HOT>(x, xh, col[s]);
-    for (uint32_t p = s + 1; p < e; ++p) acc += val[p] * gather_x<T, HOT>(x, xh, col[p]);
-  }
+                                                              const uint32_t* __restrict__ short_rows, uint32_t ns,
+                                                              T* __restrict__ y) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const uint32_t s = res_ptr[i], e = res_ptr[i + 1];
+  const uint32_t r = short_rows[i];
+  const uint32_t s1 = s + 1 < e ? s + 1 : s;
+  const uint32_t c0 = col[s], c1 = col[s1];
+  const T v0 = val[s], v1 = val[s1];
+  const T x0 = gather_x<T, HOT>(x, xh, c0), x1 = gather_x<T, HOT>(x, xh, c1);
+  T acc = v0 * x0;
+  if (s + 1 < e) acc += v1 * x1;
+  for (uint32_t p = s + 2; p < e; ++p) acc += val[p] * gather_x<T, HOT>(x, xh, col[p]);
   y[r] = acc;
 }
 
@@ -671,7 +838,7 @@ template <class T>
 __global__ void sliced_build_tables_kernel(const T* __restrict__ x, const uint32_t* __restrict__ dest, uint32_t cols,
                                            T* __restrict__ xh, uint32_t* __restrict__ heads) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < NSLAB) heads[i * HEAD_STRIDE] = 0;
+  if (i < NPART) heads[i * HEAD_STRIDE] = 0;
   if (i >= cols) return;
   const uint32_t d = dest[i];
   if (d != NO_DEST) xh[d] = x[i];
@@ -694,7 +861,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t v) {
 // consecutive columns of a level gives one column to every slab, so a slab's slots rise with the column index inside
 // each level.  Which member goes to which slab is rotated by a hash of the group number: in R-MAT the popularity of
 // a column follows its low bits, and a fixed member -> slab rule hands one slab several times the entries of
-// another.  Everything else is cold (gathered from x itself) and rotated the same way.
+// another.  Everything else is cold: part NSLAB, gathered from x itself.
 __global__ void sliced_assign_kernel(const uint32_t* __restrict__ f0, const uint32_t* __restrict__ f1,
                                      const uint64_t* __restrict__ p0, const uint64_t* __restrict__ p1, uint32_t cols,
                                      uint32_t L, uint32_t S, uint32_t line_slots, uint32_t* __restrict__ code,
@@ -710,25 +877,41 @@ __global__ void sliced_assign_kernel(const uint32_t* __restrict__ f0, const uint
     const uint32_t g = (uint32_t)(p / NSLAB), j = L + g, k = ((uint32_t)(p % NSLAB) + mix32(g ^ 0x9E3779B9u)) & (NSLAB - 1);
     code[i] = j, slab[i] = (uint8_t)k, dest[i] = k * S + j;
   } else {
-    const uint32_t c = (uint32_t)i;
-    code[i] = S + c, slab[i] = (uint8_t)((c + mix32(c >> 3)) & (NSLAB - 1)), dest[i] = NO_DEST;
+    code[i] = (uint32_t)i, slab[i] = (uint8_t)NSLAB, dest[i] = NO_DEST;
   }
 }
 __global__ void sliced_row_flags_kernel(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t long_min,
-                                        uint32_t* __restrict__ is_long, uint32_t* __restrict__ short_len) {
+                                        uint32_t* __restrict__ is_long, uint32_t* __restrict__ short_len,
+                                        uint32_t* __restrict__ is_short) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   const uint32_t len = row_ptr[r + 1] - row_ptr[r];
   const bool lg = len >= long_min;
   is_long[r] = lg;
   short_len[r] = lg ? 0u : len;
+  is_short[r] = !lg && len > 0;
+}
+// compact row list + compact row_ptr of the non-empty short rows
+__global__ void sliced_short_list_kernel(const uint32_t* __restrict__ is_short, const uint64_t* __restrict__ pos,
+                                         const uint32_t* __restrict__ res_ptr_full, uint32_t rows, uint32_t ns,
+                                         uint32_t* __restrict__ short_rows, uint32_t* __restrict__ res_ptr) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > rows) return;
+  if (r == rows) {
+    res_ptr[ns] = res_ptr_full[rows];
+    return;
+  }
+  if (is_short[r]) {
+    short_rows[pos[r]] = (uint32_t)r;
+    res_ptr[pos[r]] = res_ptr_full[r];
+  }
 }
 __global__ void sliced_long_list_kernel(const uint32_t* __restrict__ is_long, const uint64_t* __restrict__ pos, uint32_t rows,
                                         uint32_t* __restrict__ long_rows) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r < rows && is_long[r]) long_rows[pos[r]] = (uint32_t)r;
 }
-// One wavefront per long row: entries per slab.
+// One wavefront per long row: entries per part (8 slabs + cold).
 __global__ void sliced_count_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                     const uint8_t* __restrict__ slab, const uint32_t* __restrict__ long_rows, uint32_t nl,
                                     uint32_t* __restrict__ cnt8) {
@@ -739,14 +922,14 @@ __global__ void sliced_count_kernel(const uint32_t* __restrict__ row_ptr, const 
   const uint32_t s = row_ptr[r], e = row_ptr[r + 1];
   uint32_t n = 0;
   for (uint32_t p = s; p < e; p += 64) {
-    const uint32_t k = (p + lane < e) ? slab[col[p + lane]] : NSLAB;
+    const uint32_t k = (p + lane < e) ? slab[col[p + lane]] : NPART;
 #pragma unroll
-    for (uint32_t kk = 0; kk < NSLAB; ++kk) {
+    for (uint32_t kk = 0; kk < NPART; ++kk) {
       const uint64_t m = __ballot(k == kk);
       if (lane == kk) n += (uint32_t)__popcll(m);
     }
   }
-  if (lane < NSLAB) cnt8[(uint64_t)lane * nl + w] = n;
+  if (lane < NPART) cnt8[(uint64_t)lane * nl + w] = n;
 }
 // One wavefront per long row: move its entries into the slab arrays, storage order kept inside every (row, slab).
 template <class T>
@@ -760,12 +943,12 @@ __global__ void sliced_fill_kernel(const uint32_t* __restrict__ row_ptr, const u
   if (w >= nl) return;
   const uint32_t r = long_rows[w];
   const uint32_t s = row_ptr[r], e = row_ptr[r + 1];
-  uint64_t mybase = 0;  // lane kk < 8: next free position of slab kk for this row
-  if (lane < NSLAB) mybase = sbase[lane] + srow_ptr[(uint64_t)lane * (nl + 1) + w];
+  uint64_t mybase = 0;  // lane kk < NPART: next free position of part kk for this row
+  if (lane < NPART) mybase = sbase[lane] + srow_ptr[(uint64_t)lane * (nl + 1) + w];
   const uint64_t lt = (1ull << lane) - 1ull;
   for (uint32_t p = s; p < e; p += 64) {
     const bool act = p + lane < e;
-    uint32_t c = 0, k = NSLAB;
+    uint32_t c = 0, k = NPART;
     T v = T(0);
     if (act) {
       c = col[p + lane];
@@ -774,7 +957,7 @@ __global__ void sliced_fill_kernel(const uint32_t* __restrict__ row_ptr, const u
     }
     uint64_t dst = 0;
 #pragma unroll
-    for (uint32_t kk = 0; kk < NSLAB; ++kk) {
+    for (uint32_t kk = 0; kk < NPART; ++kk) {
       const uint64_t m = __ballot(k == kk);
       const uint64_t b = __shfl(mybase, (int)kk, 64);
       if (k == kk) dst = b + (uint64_t)__popcll(m & lt);
@@ -807,8 +990,10 @@ __global__ void zero_u32_kernel(uint32_t* __restrict__ p, uint64_t n) {
 
 template <class T, int TPB, int NPT, bool LDS>
 static int sliced_launch_variant(const SlicedPlan* q, const T* x, hipStream_t s, unsigned* grid_out) {
-  auto kern = spmv_sliced_kernel<T, TPB, NPT, LDS>;
-  const size_t dyn = LDS ? (size_t)q->L * sizeof(T) : 0;
+  auto kern = q->pipelined ? (env_int("SPAM_SPMV_PROF", 0) == 2 ? spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 2>
+                                                                : spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 0>)
+                           : spmv_sliced_kernel<T, TPB, NPT, LDS, 0>;
+  const size_t dyn = LDS ? (size_t)q->L * sizeof(T) : 0;  // LDS <=> q->use_lds
   if (grid_out) {
     if (dyn > 48 * 1024) SPAM_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     int per_cu = 0, dev = 0, cus = 0;
@@ -831,16 +1016,10 @@ static int sliced_launch_variant(const SlicedPlan* q, const T* x, hipStream_t s,
 
 template <class T>
 static int sliced_dispatch(const SlicedPlan* q, const T* x, hipStream_t s, unsigned* grid_out) {
-  if (!grid_out && q->tpb == 256 && q->npt == 16 && !q->L) {
+  if (!grid_out && q->tpb == 256 && q->npt == 16 && !q->use_lds && !q->pipelined) {
     const int prof = env_int("SPAM_SPMV_PROF", 0);
     if (prof == 2) {  // experiment: phase 1 only (wrong results)
       spmv_sliced_kernel<T, 256, 16, false, 2><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
-      SPAM_CHECK_LAUNCH();
-      return SPAM_OK;
-    }
-    if (prof == 3 || prof == 4) {  // experiments on the gather form
-      if (prof == 3) spmv_sliced_kernel<T, 256, 16, false, 3><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
-      else spmv_sliced_kernel<T, 256, 16, false, 4><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
       SPAM_CHECK_LAUNCH();
       return SPAM_OK;
     }
@@ -859,7 +1038,7 @@ static int sliced_dispatch(const SlicedPlan* q, const T* x, hipStream_t s, unsig
   }
 #define SPAM_SLICED_VARIANT(TPB_, NPT_)                                                         \
   if (q->tpb == TPB_ && q->npt == NPT_)                                                         \
-    return q->L ? sliced_launch_variant<T, TPB_, NPT_, true>(q, x, s, grid_out)                 \
+    return q->use_lds ? sliced_launch_variant<T, TPB_, NPT_, true>(q, x, s, grid_out)           \
                 : sliced_launch_variant<T, TPB_, NPT_, false>(q, x, s, grid_out)
   SPAM_SLICED_VARIANT(256, 16);
   SPAM_SLICED_VARIANT(256, 8);
@@ -877,9 +1056,13 @@ template <class T>
 static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPlan** out) {
   *out = nullptr;
   const int slice_kb = env_int("SPAM_SPMV_SLICE_KB", 3072);   // table bytes per XCD (of its 4 MB L2)
-  const int lds_kb = env_int("SPAM_SPMV_LDS_KB", 0);          // of which kept in LDS by every workgroup
+  // the hottest slots of every slab are laid out contiguously (they stay in the CU's L1) and, when they cover enough
+  // of the gathers to pay for the lost occupancy, copied to LDS by every workgroup.  SPAM_SPMV_LDS_KB: -1 decide
+  // (16 KB if that level covers >= 15 % of the entries), 0 never, > 0 that many KB.
+  const int lds_cfg = env_int("SPAM_SPMV_LDS_KB", -1);
+  const int l0_kb = lds_cfg > 0 ? lds_cfg : env_int("SPAM_SPMV_L0_KB", 16);
   const uint64_t smax = (uint64_t)slice_kb * 1024 / sizeof(T);
-  uint64_t lmax = (uint64_t)lds_kb * 1024 / sizeof(T);
+  uint64_t lmax = (uint64_t)(l0_kb > 0 ? l0_kb : 0) * 1024 / sizeof(T);
   if (lmax > smax) lmax = smax;
   if (!a->row_ptr32 || a->nnz == 0 || a->cols >= 0x7FFFFFFFull || a->rows >= 0xFFFFFFFFull || smax == 0) return SPAM_OK;
   if (a->cols + NSLAB * (smax + 32) >= 0xFFFFFFFFull) return SPAM_OK;
@@ -914,11 +1097,13 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
     SlicedPlan* q;
     ~Guard() { if (q) sliced_plan_free(q); }
   } guard{q};
+  q->use_lds = L > 0 && (lds_cfg > 0 || (lds_cfg < 0 && (double)m_lds >= 0.15 * (double)a->nnz));
+  q->pipelined = env_int("SPAM_SPMV_PIPE", 1) != 0;
   q->S = S, q->L = L, q->cover_table = cover_tab, q->cover_single = cover_single, q->n_table_cols = n_tab;
   {
-    const int t = env_int("SPAM_SPMV_SLICED_TPB", 256), n = env_int("SPAM_SPMV_SLICED_NPT", 0);
+    const int t = env_int("SPAM_SPMV_SLICED_TPB", 256), n = env_int("SPAM_SPMV_SLICED_NPT", 8);
     q->tpb = t == 1024 ? 1024 : (t == 512 ? 512 : 256);
-    q->npt = q->tpb == 1024 ? 4 : (q->tpb == 512 ? 8 : (n == 8 ? 8 : 16));
+    q->npt = q->tpb == 1024 ? 4 : (q->tpb == 512 ? 8 : (n == 16 ? 16 : 8));
   }
   const uint32_t tile = (uint32_t)(q->tpb * q->npt);
   {
@@ -949,24 +1134,30 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
   SPAM_CHECK_LAUNCH();
 
   // -- rows: long / short ----------------------------------------------------------------------------------
-  DevBuf is_long, short_len, posl, res64, res32;
+  DevBuf is_long, short_len, is_short, poss, posl, res64, res32;
   SPAM_TRY(is_long.alloc((uint64_t)rows * 4));
   SPAM_TRY(short_len.alloc((uint64_t)rows * 4));
+  SPAM_TRY(is_short.alloc((uint64_t)rows * 4));
+  SPAM_TRY(poss.alloc(((uint64_t)rows + 1) * 8));
   SPAM_TRY(posl.alloc(((uint64_t)rows + 1) * 8));
   SPAM_TRY(res64.alloc(((uint64_t)rows + 1) * 8));
   SPAM_TRY(res32.alloc(((uint64_t)rows + 1) * 4));
-  sliced_row_flags_kernel<<<gr, 256, 0, s>>>(a->row_ptr32, rows, q->long_min, is_long.as<uint32_t>(), short_len.as<uint32_t>());
+  sliced_row_flags_kernel<<<gr, 256, 0, s>>>(a->row_ptr32, rows, q->long_min, is_long.as<uint32_t>(), short_len.as<uint32_t>(),
+                                             is_short.as<uint32_t>());
   SPAM_CHECK_LAUNCH();
   SPAM_TRY(scan_u32_to_u64(is_long.as<uint32_t>(), rows, posl.as<uint64_t>(), tmp.p, s));
+  SPAM_TRY(scan_u32_to_u64(is_short.as<uint32_t>(), rows, poss.as<uint64_t>(), tmp.p, s));
   SPAM_TRY(scan_u32_to_u64(short_len.as<uint32_t>(), rows, res64.as<uint64_t>(), tmp.p, s));
   SPAM_TRY(narrow_row_ptr(res64.as<uint64_t>(), (uint64_t)rows + 1, res32.as<uint32_t>(), s));
-  uint64_t nl64 = 0, nnz_res = 0;
+  uint64_t nl64 = 0, nnz_res = 0, ns64 = 0;
   SPAM_HIP_TRY(hipMemcpyAsync(&nl64, posl.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(&ns64, poss.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost, s));
   SPAM_HIP_TRY(hipMemcpyAsync(&nnz_res, res64.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost, s));
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (nl64 == 0) return SPAM_OK;  // nothing to slice
   const uint32_t nl = (uint32_t)nl64;
   q->nl = nl;
+  q->ns = (uint32_t)ns64;
   q->nnz_long = a->nnz - nnz_res;
   DevBuf long_rows;
   SPAM_TRY(long_rows.alloc((uint64_t)nl * 4));
@@ -975,55 +1166,55 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
 
   // -- slab CSRs over the long rows ------------------------------------------------------------------------
   DevBuf cnt8, sc64, srow, sbase_d;
-  SPAM_TRY(cnt8.alloc((uint64_t)NSLAB * nl * 4));
+  SPAM_TRY(cnt8.alloc((uint64_t)NPART * nl * 4));
   SPAM_TRY(sc64.alloc(((uint64_t)nl + 1) * 8));
-  SPAM_TRY(srow.alloc((uint64_t)NSLAB * (nl + 1) * 4));
-  SPAM_TRY(sbase_d.alloc(NSLAB * 8));
+  SPAM_TRY(srow.alloc((uint64_t)NPART * (nl + 1) * 4));
+  SPAM_TRY(sbase_d.alloc(NPART * 8));
   const unsigned gw = (unsigned)(((uint64_t)nl * 64 + 255) / 256);
   sliced_count_kernel<<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, slab.as<uint8_t>(), long_rows.as<uint32_t>(), nl,
                                          cnt8.as<uint32_t>());
   SPAM_CHECK_LAUNCH();
   DevBuf tmp2;
   SPAM_TRY(tmp2.alloc(scan_tmp_bytes(nl)));
-  uint64_t ne[NSLAB];
-  for (int k = 0; k < NSLAB; ++k) {
+  uint64_t ne[NPART];
+  for (int k = 0; k < NPART; ++k) {
     SPAM_TRY(scan_u32_to_u64(cnt8.as<uint32_t>() + (uint64_t)k * nl, nl, sc64.as<uint64_t>(), tmp2.p, s));
     SPAM_TRY(narrow_row_ptr(sc64.as<uint64_t>(), (uint64_t)nl + 1, srow.as<uint32_t>() + (uint64_t)k * (nl + 1), s));
     SPAM_HIP_TRY(hipMemcpyAsync(&ne[k], sc64.as<uint64_t>() + nl, 8, hipMemcpyDeviceToHost, s));
     SPAM_HIP_TRY(hipStreamSynchronize(s));
   }
-  uint64_t sbase[NSLAB + 1];
-  uint32_t tile_base[NSLAB + 1];
+  uint64_t sbase[NPART + 1];
+  uint32_t tile_base[NPART + 1];
   sbase[0] = 0, tile_base[0] = 0;
-  for (int k = 0; k < NSLAB; ++k) {
+  for (int k = 0; k < NPART; ++k) {
     sbase[k + 1] = (sbase[k] + ne[k] + 3) & ~3ull;  // 16-byte vector loads start aligned in every slab
     tile_base[k + 1] = tile_base[k] + (uint32_t)((ne[k] + tile - 1) / tile);
   }
-  q->total_tiles = tile_base[NSLAB];
-  SPAM_HIP_TRY(hipMemcpyAsync(sbase_d.p, sbase, NSLAB * 8, hipMemcpyHostToDevice, s));
+  q->total_tiles = tile_base[NPART];
+  SPAM_HIP_TRY(hipMemcpyAsync(sbase_d.p, sbase, NPART * 8, hipMemcpyHostToDevice, s));
   DevBuf scol, sval, sfo, scarry, partial, xh, descs, heads;
-  SPAM_TRY(scol.alloc((sbase[NSLAB] + 4) * 4));
-  SPAM_TRY(sval.alloc((sbase[NSLAB] + 4) * sizeof(T)));
-  SPAM_TRY(sfo.alloc(((uint64_t)q->total_tiles + NSLAB) * 4));
+  SPAM_TRY(scol.alloc((sbase[NPART] + 4) * 4));
+  SPAM_TRY(sval.alloc((sbase[NPART] + 4) * sizeof(T)));
+  SPAM_TRY(sfo.alloc(((uint64_t)q->total_tiles + NPART) * 4));
   SPAM_TRY(scarry.alloc(((uint64_t)q->total_tiles + 1) * sizeof(T)));
-  SPAM_TRY(partial.alloc((uint64_t)NSLAB * nl * sizeof(T)));
+  SPAM_TRY(partial.alloc((uint64_t)NPART * nl * sizeof(T)));
   SPAM_TRY(xh.alloc((uint64_t)NSLAB * S * sizeof(T)));
-  SPAM_TRY(descs.alloc(NSLAB * sizeof(SlabDesc<T>)));
-  SPAM_TRY(heads.alloc(NSLAB * HEAD_STRIDE * 4));
+  SPAM_TRY(descs.alloc(NPART * sizeof(SlabDesc<T>)));
+  SPAM_TRY(heads.alloc(NPART * HEAD_STRIDE * 4));
   SPAM_HIP_TRY(hipMemsetAsync(xh.p, 0, (uint64_t)NSLAB * S * sizeof(T), s));  // unused slots stay defined
-  SPAM_HIP_TRY(hipMemsetAsync(partial.p, 0, (uint64_t)NSLAB * nl * sizeof(T), s));  // a slab without entries never writes
+  SPAM_HIP_TRY(hipMemsetAsync(partial.p, 0, (uint64_t)NPART * nl * sizeof(T), s));  // a slab without entries never writes
   sliced_fill_kernel<T><<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, code.as<uint32_t>(), slab.as<uint8_t>(),
                                            long_rows.as<uint32_t>(), nl, srow.as<uint32_t>(), sbase_d.as<uint64_t>(),
                                            scol.as<uint32_t>(), sval.as<T>());
   SPAM_CHECK_LAUNCH();
-  SlabDesc<T> hd[NSLAB];
-  for (int k = 0; k < NSLAB; ++k) {
+  SlabDesc<T> hd[NPART];
+  for (int k = 0; k < NPART; ++k) {
     const uint32_t nt = tile_base[k + 1] - tile_base[k];
     uint32_t* fo_k = sfo.as<uint32_t>() + tile_base[k] + k;  // ntiles + 1 entries each
     hd[k].row_ptr = srow.as<uint32_t>() + (uint64_t)k * (nl + 1);
     hd[k].col = scol.as<uint32_t>() + sbase[k];
     hd[k].val = sval.as<T>() + sbase[k];
-    hd[k].xh = xh.as<T>() + (uint64_t)k * S;
+    hd[k].xh = k < NSLAB ? xh.as<T>() + (uint64_t)k * S : nullptr;
     hd[k].y = partial.as<T>() + (uint64_t)k * nl;
     hd[k].fo = fo_k;
     hd[k].carry = scarry.as<T>() + tile_base[k];
@@ -1034,19 +1225,26 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
   }
   SPAM_HIP_TRY(hipMemcpyAsync(descs.p, hd, sizeof(hd), hipMemcpyHostToDevice, s));
 
-  // -- residual CSR: the short rows --------------------------------------------------------------------------
+  // -- residual CSR: the non-empty short rows, compacted ---------------------------------------------------------
   spam_csr* res = new (std::nothrow) spam_csr();
   if (!res) return set_error(SPAM_E_OOM, "host allocation failed");
   q->residual = res;
-  res->rows = a->rows, res->cols = a->cols, res->nnz = nnz_res, res->dtype = a->dtype, res->is_sorted = a->is_sorted;
+  res->rows = q->ns, res->cols = a->cols, res->nnz = nnz_res, res->dtype = a->dtype, res->is_sorted = a->is_sorted;
+  DevBuf short_rows;
   {
-    DevBuf rc, rv;
+    DevBuf rc, rv, rp;
     SPAM_TRY(rc.alloc((nnz_res + 4) * 4));
     SPAM_TRY(rv.alloc((nnz_res + 4) * sizeof(T)));
+    SPAM_TRY(rp.alloc(((uint64_t)q->ns + 1) * 4));
+    SPAM_TRY(short_rows.alloc(((uint64_t)q->ns + 1) * 4));
     sliced_residual_fill_kernel<T><<<gr, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, is_long.as<uint32_t>(),
                                                       res32.as<uint32_t>(), rows, rc.as<uint32_t>(), rv.as<T>());
     SPAM_CHECK_LAUNCH();
-    res->row_ptr32 = (uint32_t*)res32.release();
+    sliced_short_list_kernel<<<(unsigned)(((uint64_t)rows + 1 + 255) / 256), 256, 0, s>>>(
+        is_short.as<uint32_t>(), poss.as<uint64_t>(), res32.as<uint32_t>(), rows, q->ns, short_rows.as<uint32_t>(),
+        rp.as<uint32_t>());
+    SPAM_CHECK_LAUNCH();
+    res->row_ptr32 = (uint32_t*)rp.release();
     res->col_idx = (uint32_t*)rc.release();
     res->vals = rv.release();
   }
@@ -1054,6 +1252,7 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
   q->dest = (uint32_t*)dest.release();
   q->xh = xh.release();
   q->long_rows = (uint32_t*)long_rows.release();
+  q->short_rows = (uint32_t*)short_rows.release();
   q->srow_ptr = (uint32_t*)srow.release();
   q->scol = (uint32_t*)scol.release();
   q->sval = sval.release();
@@ -1087,16 +1286,16 @@ static int residual_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y
     pm->xh = nullptr;
     SPAM_TRY(spmv_hot_analyse<T>(res, pm, hot_kb, s));
   }
-  const uint32_t rows = (uint32_t)a->rows;
-  const unsigned g = (rows + 255) / 256;
+  if (q->ns == 0) return SPAM_OK;
+  const unsigned g = (q->ns + 255) / 256;
   if (pm->hot_k) {
     xh_build_kernel<T><<<(pm->hot_k + 255) / 256, 256, 0, s>>>(x, pm->hot_cols, pm->hot_k, (T*)pm->xh);
     SPAM_CHECK_LAUNCH();
     spmv_short_rows_kernel<T, 2><<<g, 256, 0, s>>>(res->row_ptr32, pm->ja_hot, (const T*)res->vals, x, (const T*)pm->xh,
-                                                   rows, y);
+                                                   q->short_rows, q->ns, y);
   } else {
     spmv_short_rows_kernel<T, 0><<<g, 256, 0, s>>>(res->row_ptr32, res->col_idx, (const T*)res->vals, x, nullptr,
-                                                   rows, y);
+                                                   q->short_rows, q->ns, y);
   }
   SPAM_CHECK_LAUNCH();
   return SPAM_OK;
@@ -1105,13 +1304,14 @@ static int residual_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y
 template <class T>
 static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, hipStream_t s) {
   const uint32_t cols = (uint32_t)a->cols;
+  SPAM_HIP_TRY(hipMemsetAsync(y, 0, a->rows * sizeof(T), s));  // empty rows; every other row is written below
   sliced_build_tables_kernel<T><<<(cols + 255) / 256, 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads);
   SPAM_CHECK_LAUNCH();
   SPAM_TRY(residual_run<T>(a, q, x, y, s));
   SPAM_TRY(sliced_dispatch<T>(q, x, s, nullptr));
   const uint32_t tile = (uint32_t)(q->tpb * q->npt);
-  uint32_t max_tiles = (q->total_tiles + NSLAB - 1);  // >= any slab's tile count
-  sliced_fixup_kernel<T><<<dim3((max_tiles + 255) / 256, NSLAB), 256, 0, s>>>((const SlabDesc<T>*)q->descs, tile);
+  uint32_t max_tiles = (q->total_tiles + NPART - 1);  // >= any part's tile count
+  sliced_fixup_kernel<T><<<dim3((max_tiles + 255) / 256, NPART), 256, 0, s>>>((const SlabDesc<T>*)q->descs, tile);
   SPAM_CHECK_LAUNCH();
   sliced_reduce_kernel<T><<<(q->nl + 255) / 256, 256, 0, s>>>((const T*)q->partial, q->long_rows, q->nl, y);
   SPAM_CHECK_LAUNCH();
@@ -1235,7 +1435,7 @@ static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, 
   const int sl_cfg = allow_sliced ? env_int("SPAM_SPMV_SLICED", 1) : 0;
   int64_t sl_key = 0;
   if (sl_cfg) {
-    const char* knobs[] = {"SPAM_SPMV_SLICE_KB", "SPAM_SPMV_LDS_KB", "SPAM_SPMV_LONG", "SPAM_SPMV_SLICED_TPB", "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS"};
+    const char* knobs[] = {"SPAM_SPMV_SLICE_KB", "SPAM_SPMV_LDS_KB", "SPAM_SPMV_L0_KB", "SPAM_SPMV_LONG", "SPAM_SPMV_SLICED_TPB", "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS", "SPAM_SPMV_PIPE"};
     uint64_t h = 1469598103934665603ull + (uint64_t)sl_cfg;
     for (const char* k : knobs) h = (h ^ (uint64_t)(uint32_t)env_int(k, -1)) * 1099511628211ull;
     sl_key = (int64_t)(h >> 1) + 1;  // never 0 or -1
@@ -1319,7 +1519,7 @@ int spam_spmv_sliced_info(const spam_csr* a, int* active, uint64_t* long_rows, u
   if (long_rows) *long_rows = q ? q->nl : 0;
   if (nnz_long) *nnz_long = q ? q->nnz_long : 0;
   if (table_slots) *table_slots = q ? q->S : 0;
-  if (lds_slots) *lds_slots = q ? q->L : 0;
+  if (lds_slots) *lds_slots = q ? q->L : 0;  // contiguous hottest slots (L1-resident; in LDS with SPAM_SPMV_LDS_KB)
   if (cover_table) *cover_table = q ? q->cover_table : 0.0;
   if (cover_single) *cover_single = q ? q->cover_single : 0.0;
   if (ms_plain) *ms_plain = q ? q->ms_plain : 0.0;

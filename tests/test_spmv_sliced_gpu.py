@@ -21,7 +21,7 @@ F64_RTOL = 1e-10
 F32_RTOL = 3e-5
 
 ENV_KEYS = ("SPAM_SPMV_SLICED", "SPAM_SPMV_SLICE_KB", "SPAM_SPMV_LDS_KB", "SPAM_SPMV_LONG", "SPAM_SPMV_SLICED_TPB",
-            "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS")
+            "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS", "SPAM_SPMV_L0_KB", "SPAM_SPMV_PIPE")
 
 
 @pytest.fixture
@@ -64,7 +64,8 @@ def _check(spam, oracle, off, idx, val, rows, cols, is_sorted, rtol, expect_acti
 @pytest.mark.parametrize("cfg", [dict(SLICE_KB=4), dict(SLICE_KB=4, LDS_KB=1), dict(SLICE_KB=16, LDS_KB=4, LONG=1),
                                  dict(SLICE_KB=2, LONG=40), dict(SLICE_KB=8, LDS_KB=8, SLICED_TPB=1024),
                                  dict(SLICE_KB=8, SLICED_TPB=512), dict(SLICE_KB=4, SLICED_WGS=1),
-                                 dict(SLICE_KB=4, LDS_KB=2, SLICED_NPT=8)])
+                                 dict(SLICE_KB=4, LDS_KB=2, SLICED_NPT=8), dict(SLICE_KB=4, L0_KB=0), dict(SLICE_KB=4, L0_KB=1), dict(SLICE_KB=4, PIPE=0),
+                                 dict(SLICE_KB=4, LDS_KB=1, PIPE=0, SLICED_TPB=512)])
 @pytest.mark.parametrize("scale", [9, 14])
 def test_rmat_f64_forced(spam, oracle, sliced_env, cfg, scale):
     sliced_env(**cfg)
@@ -123,7 +124,7 @@ def test_randomized_shapes_forced(spam, oracle, sliced_env):
     for case in range(60):
         sliced_env(SLICE_KB=int(rng.choice([1, 2, 8, 32])), LDS_KB=int(rng.choice([0, 0, 1, 4])),
                    LONG=int(rng.choice([1, 2, 5, 17])), SLICED_TPB=int(rng.choice([256, 512, 1024])),
-                   SLICED_NPT=int(rng.choice([8, 16])))
+                   SLICED_NPT=int(rng.choice([8, 16])), PIPE=int(rng.choice([0, 1, 1])))
         rows, cols = int(rng.integers(1, 30_001)), int(rng.integers(1, 50_001))
         kind = case % 4
         if kind == 0:

@@ -6,9 +6,9 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_bench
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
-for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum" "TCP_TCC_READ_REQ_sum"; do
   name=$(echo $grp | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --spgemm-scale 0 > /dev/null 2> $OUT/pmc_$name.log || echo "pmc $grp failed" >> $OUT/errors.log
+  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --spgemm-scale 0 > /dev/null 2> $OUT/pmc_$name.log || echo "pmc $grp failed" >> $OUT/errors.log
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
@@ -27,7 +27,7 @@ with open(out + "/summary.txt", "w") as fh:
             k = (row["Kernel_Name"][:70], row["Counter_Name"])
             agg[k][0] += float(row["Counter_Value"]); agg[k][1] += 1
         for (k, c), (v, n) in sorted(agg.items()):
-            if "spam::spmv" in k:
+            if "spam::spmv" in k or "spam::sliced" in k or "xh_build" in k:
                 fh.write("%-70s %-24s %14.6g (n=%d)\n" % (k, c, v / n, n))
 print(open(out + "/summary.txt").read())
 PY

@@ -57,13 +57,15 @@ __global__ __launch_bounds__(TPB) void gather_kernel(const uint32_t* __restrict_
 
 // Closer to the SpMV tile: VAL streams 8 more bytes per gather (non-temporal), LDSW stages the products in LDS behind a
 // barrier and lets every thread sum 16 consecutive ones afterwards.
-template <class T, bool VAL, bool LDSW>
+template <class T, bool VAL, bool LDSW, int LDSK = 0>
 __global__ __launch_bounds__(TPB) void gather2_kernel(const uint32_t* __restrict__ idx, const T* __restrict__ vals,
                                                       const T* __restrict__ table, T* __restrict__ out, uint32_t tiles_per_slab,
-                                                      uint32_t* __restrict__ heads) {
+                                                      uint32_t* __restrict__ heads, uint32_t slice = 0) {
   __shared__ uint32_t s_t;
   __shared__ T prod[TILE + TILE / 32 + 1];
+  __shared__ T ltab[LDSK ? LDSK : 1];
   const uint32_t xcc = xcc_id() & 7;
+  if (LDSK) for (int j = threadIdx.x; j < LDSK; j += TPB) ltab[j] = table[(uint64_t)xcc * slice + j];
   typedef T VT __attribute__((ext_vector_type(16 / sizeof(T))));
   constexpr int VN = 16 / sizeof(T);
   T acc = 0;
@@ -89,7 +91,10 @@ __global__ __launch_bounds__(TPB) void gather2_kernel(const uint32_t* __restrict
 #pragma unroll
     for (int i = 0; i < NPT / 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xv[i][j] = table[c[i][j]];
+      for (int j = 0; j < 4; ++j) {
+        if (LDSK) { const uint32_t loc = c[i][j] - xcc * slice; if (loc < (uint32_t)LDSK) xv[i][j] = ltab[loc]; else xv[i][j] = table[c[i][j]]; }
+        else xv[i][j] = table[c[i][j]];
+      }
 #pragma unroll
     for (int i = 0; i < NPT / 4; ++i)
 #pragma unroll
@@ -113,6 +118,7 @@ __global__ void fill_idx2(uint32_t* idx, uint64_t n, uint32_t tiles_per_slab, ui
   const uint64_t slab = i / ((uint64_t)tiles_per_slab * TILE);
   uint64_t h = mix(i + seed), v;
   if (skew_bits == 0) v = h % slice;
+  else if (skew_bits < 0) v = ((h >> 40) % 100 < (uint64_t)(-skew_bits)) ? (h % 2048) : (2048 + h % (slice - 2048));
   else {
     v = 0; uint64_t hh = h;
     for (int b = 0; b < skew_bits; ++b) { if ((b & 3) == 0) hh = mix(h + b); uint32_t u = (hh >> (16 * (b & 3))) & 0xFFFF; v = (v << 1) | (u >= 49807u); }
@@ -121,7 +127,7 @@ __global__ void fill_idx2(uint32_t* idx, uint64_t n, uint32_t tiles_per_slab, ui
   idx[i] = (uint32_t)(slab * slice + v);
 }
 
-template <class T, bool VAL, bool LDSW>
+template <class T, bool VAL, bool LDSW, int LDSK = 0>
 int run2(double slice_mb, int wg_per_cu, int skew_bits) {
   const uint32_t tiles_per_slab = 4096;
   const uint64_t n = (uint64_t)tiles_per_slab * 8 * TILE;
@@ -138,14 +144,14 @@ int run2(double slice_mb, int wg_per_cu, int skew_bits) {
   for (int r = -2; r < reps; ++r) {
     CK(hipMemsetAsync(heads, 0, 8 * 256, 0));
     CK(hipEventRecord(a));
-    gather2_kernel<T, VAL, LDSW><<<grid, TPB>>>(idx, vals, table, out, tiles_per_slab, heads);
+    gather2_kernel<T, VAL, LDSW, LDSK><<<grid, TPB>>>(idx, vals, table, out, tiles_per_slab, heads, (uint32_t)slice);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float m; CK(hipEventElapsedTime(&m, a, b));
     if (r >= 0) tot += m;
   }
   const float ms = tot / reps;
-  printf("tile-like: elem %zuB slice %.2f MB, %d WG/CU, skew bits %2d, val stream %d, LDS staging %d: %.3f ms %.1f Ggather/s\n", sizeof(T), slice_mb,
-         wg_per_cu, skew_bits, (int)VAL, (int)LDSW, ms, n / ms / 1e6);
+  printf("tile-like: elem %zuB slice %.2f MB, %d WG/CU, skew bits %2d, val stream %d, LDS staging %d, LDS table %d slots: %.3f ms %.1f Ggather/s\n", sizeof(T), slice_mb,
+         wg_per_cu, skew_bits, (int)VAL, (int)LDSW, LDSK, ms, n / ms / 1e6);
   CK(hipFree(idx)); CK(hipFree(vals)); CK(hipFree(table)); CK(hipFree(out)); CK(hipFree(heads));
   return 0;
 }
@@ -196,6 +202,13 @@ int run(double slice_mb, int wg_per_cu) {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 2) {  // third series: a share of the gathers served from a 2048-slot LDS table (skew -P = P percent)
+    for (int pct : {0, 30, 50, 70}) {
+      run2<double, true, true, 0>(2.75, 3, -pct);
+      run2<double, true, true, 2048>(2.75, 3, -pct);
+    }
+    return 0;
+  }
   if (argc > 1) {  // second series: morph the loop towards the SpMV tile
     for (int skew : {0, 19}) {
       run2<double, false, false>(2.75, 4, skew);
