@@ -134,6 +134,15 @@ __device__ __forceinline__ T dpp_shift(T v) {
     return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
   }
 }
+// Sum over each 16-lane row of the wavefront: the total of lanes 16g .. 16g+15 arrives in lane 16g+15.
+template <class T>
+__device__ __forceinline__ T row16_sum_lane15(T v) {
+  v += dpp_shift<0x111, 0xF>(v);
+  v += dpp_shift<0x112, 0xF>(v);
+  v += dpp_shift<0x114, 0xF>(v);
+  v += dpp_shift<0x118, 0xF>(v);
+  return v;
+}
 template <class T>
 __device__ __forceinline__ T wave_sum_lane63(T v) {
   v += dpp_shift<0x111, 0xF>(v);  // row_shr:1
@@ -175,8 +184,11 @@ struct TileSmem {
   static_assert(TILE <= 65535 && RCAP % TPB == 0, "tile-local offsets are kept as u16");
   T prod[TILE + TILE / 32 + 1];
   uint16_t rp[RCAP];
-  uint32_t long_list[MAXLONG];
-  uint32_t n_long;
+  static constexpr int MID_ROW = 256;          // rows of SHORT_ROW+1 .. MID_ROW entries: 16 lanes each, longer: a wavefront
+  static constexpr int MAXBIG = TILE / (MID_ROW + 1) + 2;
+  uint32_t long_list[MAXLONG];                 // mid rows
+  uint32_t big_list[MAXBIG];
+  uint32_t n_long, n_big;
 };
 
 // In-kernel phase timers (SPAM_SPMV_PROF=1, sliced kernel only; results unaffected): cycles of wave 0 summed over
@@ -262,7 +274,7 @@ __device__ __forceinline__ void tile_finish(const TileRegs<T, OffT, TPB, NPT>& r
 
 // Step 3 (after a barrier): per-row sums of the tile's `cnt` products, everything from LDS.  sm.rp holds the first
 // min(nv, RCAP) tile-local offsets of rows f0 .. f1; tiles with more rows (runs of empty or one-entry rows) restage.
-// sm.n_long must be 0 on entry.
+// sm.n_long and sm.n_big must be 0 on entry.
 template <class T, class OffT, int TPB, int NPT, int PROF = 0>
 __device__ __forceinline__ void tile_phase2(TileSmem<T, TPB, NPT>& sm, const OffT SPAM_GLB* __restrict__ row_ptr,
                                             T SPAM_GLB* __restrict__ y, T SPAM_GLB* __restrict__ carry, uint32_t f0,
@@ -274,39 +286,119 @@ __device__ __forceinline__ void tile_phase2(TileSmem<T, TPB, NPT>& sm, const Off
   uint32_t* long_list = sm.long_list;
   const int tid = threadIdx.x;
   const uint32_t nv = f1 - f0 + 1;  // row_ptr values of this tile: rows f0 .. f1 - 1 plus the closing offset
+  const uint32_t cnt1 = (uint32_t)(end - base);
   const int lane = tid & 63, wave = tid >> 6;
   uint32_t row0 = 0;                // rows finished in earlier passes
   for (;;) {
     const uint32_t n = (nv - row0) < (uint32_t)RCAP ? (nv - row0) : (uint32_t)RCAP;  // staged values rp[0 .. n)
     const uint32_t nr = n - 1;                                                       // complete rows of this pass
     // row f0-1 started in an earlier tile: its piece [0, rp[0]) goes to carry[tile]
-    if (row0 == 0 && tid == 0 && f0 > 0 && sm.rp[0] > 0) long_list[atomicAdd(&sm.n_long, 1u)] = CARRY;
-    for (uint32_t i = tid; i < nr; i += TPB) {
-      const uint32_t s = sm.rp[i], e = sm.rp[i + 1];
-      const uint32_t len = e - s;
-      if (len <= SHORT_ROW) {
-        // left to right (the oracle's order); four LDS reads are issued together so their latencies overlap
+    if (row0 == 0 && tid == 0 && f0 > 0 && sm.rp[0] > 0) {
+      if (sm.rp[0] > (uint32_t)SM::MID_ROW)
+        sm.big_list[atomicAdd(&sm.n_big, 1u)] = CARRY;
+      else
+        long_list[atomicAdd(&sm.n_long, 1u)] = CARRY;
+    }
+    // short rows: one lane per row, two rows per lane and round so that their LDS reads overlap; each row is summed
+    // left to right (the oracle's order), the first four products of both rows are read together
+    for (uint32_t i = tid; i < nr; i += 2 * TPB) {
+      const uint32_t i2 = i + TPB;
+      const bool has2 = i2 < nr;
+      const uint32_t s1 = sm.rp[i], e1 = sm.rp[i + 1];
+      const uint32_t s2 = has2 ? sm.rp[i2] : 0u, e2 = has2 ? sm.rp[i2 + 1] : 0u;
+      const uint32_t len1 = e1 - s1, len2 = e2 - s2;
+      const uint32_t last = cnt1 - 1;  // any valid product slot for the clamped reads
+      T p[4], q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        p[k] = prod[pad_idx((int)(s1 + k < e1 ? s1 + k : last))];
+        q[k] = prod[pad_idx((int)(s2 + k < e2 ? s2 + k : last))];
+      }
+      if (len1 <= SHORT_ROW) {
         T acc = T(0);
-        uint32_t k = 0;
-        for (; k + 4 <= len; k += 4) {
-          const T p0 = prod[pad_idx((int)(s + k))], p1 = prod[pad_idx((int)(s + k + 1))];
-          const T p2 = prod[pad_idx((int)(s + k + 2))], p3 = prod[pad_idx((int)(s + k + 3))];
-          acc = k ? acc + p0 : p0;
-          acc += p1;
-          acc += p2;
-          acc += p3;
+        if (len1) {
+          acc = p[0];
+#pragma unroll
+          for (int k = 1; k < 4; ++k)
+            if ((uint32_t)k < len1) acc += p[k];
+          uint32_t k = 4;
+          for (; k + 4 <= len1; k += 4) {
+            const T p0 = prod[pad_idx((int)(s1 + k))], p1 = prod[pad_idx((int)(s1 + k + 1))];
+            const T p2 = prod[pad_idx((int)(s1 + k + 2))], p3 = prod[pad_idx((int)(s1 + k + 3))];
+            acc += p0;
+            acc += p1;
+            acc += p2;
+            acc += p3;
+          }
+          for (; k < len1; ++k) acc += prod[pad_idx((int)(s1 + k))];
         }
-        for (; k < len; ++k) acc = k ? acc + prod[pad_idx((int)(s + k))] : prod[pad_idx((int)(s + k))];
         y[f0 + row0 + i] = acc;
-      } else {
+      } else if (len1 <= (uint32_t)SM::MID_ROW) {
         long_list[atomicAdd(&sm.n_long, 1u)] = i;
+      } else {
+        sm.big_list[atomicAdd(&sm.n_big, 1u)] = i;
+      }
+      if (has2) {
+        if (len2 <= SHORT_ROW) {
+          T acc = T(0);
+          if (len2) {
+            acc = q[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+              if ((uint32_t)k < len2) acc += q[k];
+            uint32_t k = 4;
+            for (; k + 4 <= len2; k += 4) {
+              const T p0 = prod[pad_idx((int)(s2 + k))], p1 = prod[pad_idx((int)(s2 + k + 1))];
+              const T p2 = prod[pad_idx((int)(s2 + k + 2))], p3 = prod[pad_idx((int)(s2 + k + 3))];
+              acc += p0;
+              acc += p1;
+              acc += p2;
+              acc += p3;
+            }
+            for (; k < len2; ++k) acc += prod[pad_idx((int)(s2 + k))];
+          }
+          y[f0 + row0 + i2] = acc;
+        } else if (len2 <= (uint32_t)SM::MID_ROW) {
+          long_list[atomicAdd(&sm.n_long, 1u)] = i2;
+        } else {
+          sm.big_list[atomicAdd(&sm.n_big, 1u)] = i2;
+        }
       }
     }
     if (PROF && row0 == 0) *pt3 = clock64();
     __syncthreads();
-    const uint32_t nl = sm.n_long;
+    // mid rows (SHORT_ROW+1 .. MID_ROW entries): four at a time per wavefront, 16 lanes each
+    {
+      const uint32_t nm = sm.n_long;
+      const int grp = lane >> 4, sub = lane & 15;
+      for (uint32_t jb = (uint32_t)wave * 4; jb < nm; jb += (TPB / 64) * 4) {
+        const uint32_t j = jb + grp;
+        const bool valid = j < nm;
+        const uint32_t i = valid ? long_list[j] : 0u;
+        uint32_t s = 0, e = 0;
+        if (valid) {
+          if (i == CARRY) {
+            e = sm.rp[0];
+          } else {
+            s = sm.rp[i];
+            e = sm.rp[i + 1];
+          }
+        }
+        T acc = T(0);
+        for (int pp = (int)s + sub, pe = (int)e; pp < pe; pp += 16) acc += prod[pad_idx(pp)];
+        acc = row16_sum_lane15(acc);
+        if (valid && sub == 15) {
+          if (i == CARRY)
+            carry[tile_idx] = acc;
+          else
+            y[f0 + row0 + i] = acc;
+        }
+      }
+    }
+    // big rows: one wavefront each
+    const uint32_t nl = sm.n_big;
     for (uint32_t j = wave; j < nl; j += TPB / 64) {
-      const uint32_t i = long_list[j];
+      const uint32_t i = sm.big_list[j];
       uint32_t s = 0, e;
       if (i == CARRY) {
         e = sm.rp[0];
@@ -333,7 +425,7 @@ __device__ __forceinline__ void tile_phase2(TileSmem<T, TPB, NPT>& sm, const Off
     row0 += nr;
     if (row0 + 1 >= nv) break;
     __syncthreads();  // everyone is done with rp / long_list of this pass
-    if (tid == 0) sm.n_long = 0;
+    if (tid == 0) sm.n_long = 0, sm.n_big = 0;
     const uint32_t n2 = (nv - row0) < (uint32_t)RCAP ? (nv - row0) : (uint32_t)RCAP;
     for (uint32_t i = tid; i < n2; i += TPB) {
       const uint64_t rv = (uint64_t)row_ptr[f0 + row0 + i];
@@ -360,7 +452,7 @@ __device__ __forceinline__ void spmv_tile_body(TileSmem<T, TPB, NPT>& sm, const 
   const uint64_t base = (uint64_t)tile_idx * TILE;
   const uint32_t cnt = (uint32_t)((nnz - base) < (uint64_t)TILE ? (nnz - base) : (uint64_t)TILE);
   const uint64_t end = base + cnt;
-  if (tid == 0) sm.n_long = 0;
+  if (tid == 0) sm.n_long = 0, sm.n_big = 0;
   long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
   if (PROF) pt0 = clock64();
   uint32_t f0, f1;
@@ -666,8 +758,14 @@ struct GatherSliced {
   bool cold;
   __device__ __forceinline__ T operator()(uint32_t c) const {
     if (cold) return __builtin_nontemporal_load(base + c);
-    if (c < L) return lds[c];
-    return base[c];
+    if (L == 0) return base[c];
+    // branch-free: a per-lane branch between an LDS read and a global load makes the compiler wait for every gather
+    // before it issues the next one (the whole tile then costs 8 serial L2 round trips).  Lanes served by LDS point
+    // their global load at slot 0 — identical addresses collapse into one request per wave instruction.
+    const bool in_lds = c < L;
+    const T g = base[in_lds ? 0u : c];
+    const T l = lds[in_lds ? c : 0u];
+    return in_lds ? l : g;
   }
 };
 
@@ -757,27 +855,44 @@ __global__ __launch_bounds__(TPB) void spmv_sliced_pipe_kernel(const SlabDesc<T>
       uint32_t t_nn = 0;
       if (threadIdx.x == 0) {
         t_nn = atomicAdd(head, 1u);
-        sm.n_long = 0;
+        sm.n_long = 0, sm.n_big = 0;
       }
       if (loaded) {
+        long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+        if (PROF == 1) q0 = clock64();
         tile_finish<T, uint32_t, TPB, NPT>(r, sm, t_cur);
         const uint32_t f0 = r.f0, f1 = r.f1;
+        if (PROF == 1) q1 = clock64();
         __syncthreads();
+        if (PROF == 1) q2 = clock64();
         loaded = t_next < nfull;
         if (loaded) tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, gx, fo, t_next);
+        if (PROF == 1) q3 = clock64();
         const uint64_t base = (uint64_t)t_cur * TILE;
         if (PROF != 2)  // 2: experiment, loads and products only (wrong results)
-          tile_phase2<T, uint32_t, TPB, NPT>(sm, row_ptr, y, carry, f0, f1, base, base + TILE, t_cur, nullptr);
+          tile_phase2<T, uint32_t, TPB, NPT, (PROF == 1 ? 1 : 0)>(sm, row_ptr, y, carry, f0, f1, base, base + TILE, t_cur, &q4);
+        if (PROF == 1 && threadIdx.x == 0) {  // [0] wait for gathers + products, [1] barrier, [2] issue next, [3] short rows, [4] long rows
+          const long long q5 = clock64();
+          atomicAdd(&g_spmv_prof[0], (unsigned long long)(q1 - q0));
+          atomicAdd(&g_spmv_prof[1], (unsigned long long)(q2 - q1));
+          atomicAdd(&g_spmv_prof[2], (unsigned long long)(q3 - q2));
+          atomicAdd(&g_spmv_prof[3], (unsigned long long)(q4 - q3));
+          atomicAdd(&g_spmv_prof[4], (unsigned long long)(q5 - q4));
+          atomicAdd(&g_spmv_prof[5], 1ull);
+        }
       } else {
         spmv_tile_body<T, uint32_t, TPB, NPT, true>(sm, row_ptr, col, val, gx, y, fo, carry, sd.nnz, t_cur);
         loaded = t_next < nfull;
         if (loaded) tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, gx, fo, t_next);
       }
+      long long q6 = 0;
+      if (PROF == 1) q6 = clock64();
       if (threadIdx.x == 0) s_t[0] = t_nn;
       __syncthreads();
       t_cur = t_next;
       t_next = s_t[0];
       __syncthreads();
+      if (PROF == 1 && threadIdx.x == 0) atomicAdd(&g_spmv_prof[6], (unsigned long long)(clock64() - q6));
     }
   }
 }
@@ -809,27 +924,39 @@ __global__ void sliced_reduce_kernel(const T* __restrict__ partial, const uint32
   y[long_rows[i]] = acc;
 }
 
-// The non-empty rows of fewer than long_min entries (compacted): one lane per row, summed left to right — the
-// oracle's order, so these rows are bit-identical to it.  The first two entries are loaded together (the kernel is
-// latency-bound: every entry is a chain of two dependent loads).  y was zero-filled before (empty rows).
+// The non-empty rows of fewer than long_min entries (compacted): two rows per lane (rows i and i + half), each summed
+// left to right — the oracle's order, so these rows are bit-identical to it.  The first two entries of both rows are
+// loaded together: the kernel is latency-bound, every entry is a chain of two dependent loads, so a lane keeps four
+// chains in flight.  y was zero-filled before (empty rows).
 template <class T, int HOT>
 __global__ __launch_bounds__(256) void spmv_short_rows_kernel(const uint32_t* __restrict__ res_ptr,
                                                               const uint32_t* __restrict__ col, const T* __restrict__ val,
                                                               const T* __restrict__ x, const T* __restrict__ xh,
                                                               const uint32_t* __restrict__ short_rows, uint32_t ns,
                                                               T* __restrict__ y) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ns) return;
-  const uint32_t s = res_ptr[i], e = res_ptr[i + 1];
-  const uint32_t r = short_rows[i];
-  const uint32_t s1 = s + 1 < e ? s + 1 : s;
-  const uint32_t c0 = col[s], c1 = col[s1];
-  const T v0 = val[s], v1 = val[s1];
-  const T x0 = gather_x<T, HOT>(x, xh, c0), x1 = gather_x<T, HOT>(x, xh, c1);
-  T acc = v0 * x0;
-  if (s + 1 < e) acc += v1 * x1;
-  for (uint32_t p = s + 2; p < e; ++p) acc += val[p] * gather_x<T, HOT>(x, xh, col[p]);
-  y[r] = acc;
+  const uint32_t half = (ns + 1) / 2;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= half) return;
+  const uint32_t i2 = i + half;
+  const bool has2 = i2 < ns;
+  const uint32_t ib = has2 ? i2 : i;
+  const uint32_t sa = res_ptr[i], ea = res_ptr[i + 1], sb = res_ptr[ib], eb = res_ptr[ib + 1];
+  const uint32_t ra = short_rows[i], rb = short_rows[ib];
+  const uint32_t sa1 = sa + 1 < ea ? sa + 1 : sa, sb1 = sb + 1 < eb ? sb + 1 : sb;
+  const uint32_t ca0 = col[sa], ca1 = col[sa1], cb0 = col[sb], cb1 = col[sb1];
+  const T va0 = val[sa], va1 = val[sa1], vb0 = val[sb], vb1 = val[sb1];
+  const T xa0 = gather_x<T, HOT>(x, xh, ca0), xa1 = gather_x<T, HOT>(x, xh, ca1);
+  const T xb0 = gather_x<T, HOT>(x, xh, cb0), xb1 = gather_x<T, HOT>(x, xh, cb1);
+  T acc = va0 * xa0;
+  if (sa + 1 < ea) acc += va1 * xa1;
+  for (uint32_t p = sa + 2; p < ea; ++p) acc += val[p] * gather_x<T, HOT>(x, xh, col[p]);
+  y[ra] = acc;
+  if (has2) {
+    T acc2 = vb0 * xb0;
+    if (sb + 1 < eb) acc2 += vb1 * xb1;
+    for (uint32_t p = sb + 2; p < eb; ++p) acc2 += val[p] * gather_x<T, HOT>(x, xh, col[p]);
+    y[rb] = acc2;
+  }
 }
 
 // Rebuild the 8 slab tables from x (column order: x and dest stream, the table writes of one workgroup are
@@ -990,10 +1117,25 @@ __global__ void zero_u32_kernel(uint32_t* __restrict__ p, uint64_t n) {
 
 template <class T, int TPB, int NPT, bool LDS>
 static int sliced_launch_variant(const SlicedPlan* q, const T* x, hipStream_t s, unsigned* grid_out) {
-  auto kern = q->pipelined ? (env_int("SPAM_SPMV_PROF", 0) == 2 ? spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 2>
-                                                                : spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 0>)
-                           : spmv_sliced_kernel<T, TPB, NPT, LDS, 0>;
   const size_t dyn = LDS ? (size_t)q->L * sizeof(T) : 0;  // LDS <=> q->use_lds
+  const int prof = grid_out ? 0 : env_int("SPAM_SPMV_PROF", 0);  // 1: in-kernel phase timers, 2: no phase 2 (experiment)
+  auto kern = q->pipelined ? (prof == 2 ? spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 2>
+                                        : (prof == 1 ? spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 1>
+                                                     : spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 0>))
+                           : spmv_sliced_kernel<T, TPB, NPT, LDS, 0>;
+  if (prof == 1 && q->pipelined) {
+    unsigned long long h[8] = {0};
+    SPAM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_prof), h, sizeof(h)));
+    kern<<<q->grid, TPB, dyn, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+    SPAM_CHECK_LAUNCH();
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+    SPAM_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_spmv_prof), sizeof(h)));
+    const double n = (double)(h[5] ? h[5] : 1);
+    fprintf(stderr, "[spam] pipelined sliced SpMV, cycles per tile (wave 0): wait gathers + products %.0f, barrier %.0f, "
+            "issue next tile %.0f, short rows %.0f, barrier + long rows %.0f, ticket barriers %.0f; tiles %llu, grid %u\n",
+            h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n, h[5], q->grid);
+    return SPAM_OK;
+  }
   if (grid_out) {
     if (dyn > 48 * 1024) SPAM_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     int per_cu = 0, dev = 0, cus = 0;
@@ -1287,7 +1429,7 @@ static int residual_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y
     SPAM_TRY(spmv_hot_analyse<T>(res, pm, hot_kb, s));
   }
   if (q->ns == 0) return SPAM_OK;
-  const unsigned g = (q->ns + 255) / 256;
+  const unsigned g = ((q->ns + 1) / 2 + 255) / 256;  // two rows per lane
   if (pm->hot_k) {
     xh_build_kernel<T><<<(pm->hot_k + 255) / 256, 256, 0, s>>>(x, pm->hot_cols, pm->hot_k, (T*)pm->xh);
     SPAM_CHECK_LAUNCH();
