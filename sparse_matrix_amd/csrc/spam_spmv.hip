@@ -924,48 +924,39 @@ __global__ void sliced_reduce_kernel(const T* __restrict__ partial, const uint32
   y[long_rows[i]] = acc;
 }
 
-// The non-empty rows of fewer than long_min entries (compacted): two rows per lane (rows i and i + half), each summed
-// left to right — the oracle's order, so these rows are bit-identical to it.  The first two entries of both rows are
-// loaded together: the kernel is latency-bound, every entry is a chain of two dependent loads, so a lane keeps four
-// chains in flight.  y was zero-filled before (empty rows).
+// The non-empty rows of fewer than long_min entries (compacted): one lane per row, summed left to right — the
+// oracle's order, so these rows are bit-identical to it.  The first two entries are loaded together.  The kernel
+// moves 0.6 GB for 9 M entries on the bench matrix (a third of its gathers miss the one table these rows share and
+// fetch a 128-byte line each): it runs at the fabric rate; two or four rows per lane were measured slower.
 template <class T, int HOT>
 __global__ __launch_bounds__(256) void spmv_short_rows_kernel(const uint32_t* __restrict__ res_ptr,
                                                               const uint32_t* __restrict__ col, const T* __restrict__ val,
                                                               const T* __restrict__ x, const T* __restrict__ xh,
                                                               const uint32_t* __restrict__ short_rows, uint32_t ns,
                                                               T* __restrict__ y) {
-  const uint32_t half = (ns + 1) / 2;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= half) return;
-  const uint32_t i2 = i + half;
-  const bool has2 = i2 < ns;
-  const uint32_t ib = has2 ? i2 : i;
-  const uint32_t sa = res_ptr[i], ea = res_ptr[i + 1], sb = res_ptr[ib], eb = res_ptr[ib + 1];
-  const uint32_t ra = short_rows[i], rb = short_rows[ib];
-  const uint32_t sa1 = sa + 1 < ea ? sa + 1 : sa, sb1 = sb + 1 < eb ? sb + 1 : sb;
-  const uint32_t ca0 = col[sa], ca1 = col[sa1], cb0 = col[sb], cb1 = col[sb1];
-  const T va0 = val[sa], va1 = val[sa1], vb0 = val[sb], vb1 = val[sb1];
-  const T xa0 = gather_x<T, HOT>(x, xh, ca0), xa1 = gather_x<T, HOT>(x, xh, ca1);
-  const T xb0 = gather_x<T, HOT>(x, xh, cb0), xb1 = gather_x<T, HOT>(x, xh, cb1);
-  T acc = va0 * xa0;
-  if (sa + 1 < ea) acc += va1 * xa1;
-  for (uint32_t p = sa + 2; p < ea; ++p) acc += val[p] * gather_x<T, HOT>(x, xh, col[p]);
-  y[ra] = acc;
-  if (has2) {
-    T acc2 = vb0 * xb0;
-    if (sb + 1 < eb) acc2 += vb1 * xb1;
-    for (uint32_t p = sb + 2; p < eb; ++p) acc2 += val[p] * gather_x<T, HOT>(x, xh, col[p]);
-    y[rb] = acc2;
-  }
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const uint32_t s = res_ptr[i], e = res_ptr[i + 1];
+  const uint32_t r = short_rows[i];
+  const uint32_t s1 = s + 1 < e ? s + 1 : s;
+  const uint32_t c0 = col[s], c1 = col[s1];
+  const T v0 = val[s], v1 = val[s1];
+  const T x0 = gather_x<T, HOT>(x, xh, c0), x1 = gather_x<T, HOT>(x, xh, c1);
+  T acc = v0 * x0;
+  if (s + 1 < e) acc += v1 * x1;
+  for (uint32_t p = s + 2; p < e; ++p) acc += val[p] * gather_x<T, HOT>(x, xh, col[p]);
+  y[r] = acc;
 }
 
 // Rebuild the 8 slab tables from x (column order: x and dest stream, the table writes of one workgroup are
-// contiguous runs inside each slab) and reset the tile queues.
+// contiguous runs inside each slab), reset the tile queues and zero y (the empty rows; every other row is written later).
 template <class T>
 __global__ void sliced_build_tables_kernel(const T* __restrict__ x, const uint32_t* __restrict__ dest, uint32_t cols,
-                                           T* __restrict__ xh, uint32_t* __restrict__ heads) {
+                                           T* __restrict__ xh, uint32_t* __restrict__ heads, T* __restrict__ y,
+                                           uint32_t rows) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < NPART) heads[i * HEAD_STRIDE] = 0;
+  if (i < rows) y[i] = T(0);
   if (i >= cols) return;
   const uint32_t d = dest[i];
   if (d != NO_DEST) xh[d] = x[i];
@@ -1429,7 +1420,7 @@ static int residual_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y
     SPAM_TRY(spmv_hot_analyse<T>(res, pm, hot_kb, s));
   }
   if (q->ns == 0) return SPAM_OK;
-  const unsigned g = ((q->ns + 1) / 2 + 255) / 256;  // two rows per lane
+  const unsigned g = (q->ns + 255) / 256;
   if (pm->hot_k) {
     xh_build_kernel<T><<<(pm->hot_k + 255) / 256, 256, 0, s>>>(x, pm->hot_cols, pm->hot_k, (T*)pm->xh);
     SPAM_CHECK_LAUNCH();
@@ -1446,8 +1437,8 @@ static int residual_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y
 template <class T>
 static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, hipStream_t s) {
   const uint32_t cols = (uint32_t)a->cols;
-  SPAM_HIP_TRY(hipMemsetAsync(y, 0, a->rows * sizeof(T), s));  // empty rows; every other row is written below
-  sliced_build_tables_kernel<T><<<(cols + 255) / 256, 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads);
+  const uint32_t rows = (uint32_t)a->rows;
+  sliced_build_tables_kernel<T><<<(std::max(cols, rows) + 255) / 256, 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
   SPAM_CHECK_LAUNCH();
   // (running the short rows beside the slab kernel on a second stream was measured 3 % slower than one after the other)
   SPAM_TRY(residual_run<T>(a, q, x, y, s));
