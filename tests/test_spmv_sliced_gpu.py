@@ -161,3 +161,20 @@ def test_auto_mode_keeps_small_matrices_on_the_plain_path(spam, oracle, sliced_e
     off, idx, val = csr_np(m)
     info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL, expect_active=False)
     assert not info["active"]
+
+
+def test_row_block_view_forced(spam, oracle, sliced_env):
+    """A zero-copy row-block view (what a rank holds of a row-sharded matrix: its row_ptr starts inside the parent's
+    arrays, a few pad entries in front) through the sliced path."""
+    sliced_env(SLICE_KB=4, LDS_KB=1)
+    m = synth.rmat(12)
+    off, idx, val = csr_np(m)
+    A = spam.CsrMatrix(m.rows, m.cols, val, idx, off, True)
+    x = synth.dense_vector(m.cols).numpy()
+    ref = oracle.spmv((off, idx, val), x)
+    for lo, hi in ((1000, 3001), (0, 17), (4090, 4096)):
+        blk = A.device().row_block(lo, hi)
+        y = blk.spmv(x)
+        assert np.abs(y - ref[lo:hi]).max() <= F64_RTOL * np.abs(ref).max()
+        assert np.array_equal(y == 0, ref[lo:hi] == 0)
+    assert A.device().row_block(1000, 3001).spmv(x).shape == (2001,)
