@@ -6,28 +6,38 @@
 // y_i = 0 for rows without entries.
 //
 // Design (HBM-bound: 12 B/nnz of ja/a stream + the x gather; no MFMA, nothing here is a dense contraction):
-//   * the nnz range is cut into fixed tiles of TPB*NPT entries; workgroup t owns tile t, so every
-//     workgroup streams the same number of bytes whatever the row-length distribution (R-MAT, 50k-entry
-//     rows next to 8-entry rows) — this is the row "binning" of CSR-adaptive done per tile;
-//   * phase 1: 16-byte coalesced loads of ja / a, gather x[ja], products into an LDS tile (padded one
-//     slot per 32 so row-strided reads spread over the banks);
-//   * phase 2, adaptive per row: rows of <= SHORT_ROW entries inside the tile are summed by one lane each,
-//     left to right (bit-identical to the oracle's order); longer rows and the piece of a row that
-//     started in an earlier tile are summed by a whole wavefront with __shfl_xor;
-//   * a row spanning several tiles gets its pieces from `carry[tile]`, folded in tile order by a
-//     second tiny kernel — deterministic, no float atomics.
+//   * the nnz range is cut into fixed tiles of TPB*NPT entries, so every workgroup streams the same number of
+//     bytes whatever the row-length distribution (R-MAT, 50k-entry rows next to 8-entry rows) — this is the row
+//     "binning" of CSR-adaptive done per tile;
+//   * tile_issue: 16-byte coalesced non-temporal loads of ja / a, the x gathers, and behind them the tile's slice
+//     of row_ptr; tile_finish: products into an LDS tile (padded one slot per 32), row offsets into LDS;
+//   * tile_phase2, from LDS only: rows of <= 32 entries are summed by one lane each, left to right (bit-identical
+//     to the oracle's order), rows of <= 256 entries by 16 lanes, longer rows and row pieces by a wavefront (DPP sums);
+//   * a row spanning several tiles gets its pieces from `carry[tile]`, folded in tile order by a second tiny
+//     kernel — deterministic, no float atomics.
 //   The row -> tile map (first row starting in each tile) depends on row_ptr only and is built once per
 //   matrix (the analysis step of CSR-adaptive), then reused by every SpMV on that handle.
 //
-// XCD-sliced mode (second half of this file): when x is larger than one XCD's 4 MB L2 a random gather that
+// Plain path: spmv_tile_kernel, one workgroup per tile, optional hot-column table (one 3 MB table in every L2).
+//
+// XCD-sliced path (second half of this file): when x is larger than one XCD's 4 MB L2 a random gather that
 // misses L2 moves a whole 128-byte line over the fabric (52 G gathers/s against 245 G/s for L2 hits,
 // profiles/r01_gather_microbench.txt).  MI355X has EIGHT such L2s; tools/xcd_gather_bench.hip shows they serve
 // 230 G gathers/s from a 24-28 MB table as long as every workgroup only touches the table slice of the XCD it
-// runs on.  So the analysis deals the most referenced columns over 8 slabs (one packed x-table per XCD), splits
-// the entries of the long rows into 8 slab CSRs, and the kernel's workgroups read HW_REG_XCC_ID and pull tiles of
-// their own XCD's slab from a per-XCD queue (stealing from the others at the end, so nothing depends on the
-// placement).  Every slab yields a partial y over the long rows; a last kernel adds the 8 partials in slab order.
-// Short rows (too few entries to pay for 8 partials) stay in a residual CSR that runs through the tile kernel above.
+// runs on.  So the analysis deals the most referenced columns over 8 slabs (one packed x-table per XCD), stores
+// the rows of >= long_min entries again as 8 slab CSRs + a cold part, and the persistent, software-pipelined
+// spmv_sliced_pipe_kernel has its workgroups read HW_REG_XCC_ID and pull tiles of their own XCD's slab from a
+// per-XCD queue (then the cold part, then what other XCDs have left, so nothing depends on the placement).
+// Every part yields a partial y over the long rows; sliced_reduce_kernel adds them in part order.  Shorter rows
+// stay in a compact residual CSR (spmv_short_rows_kernel).  The first SpMV on a handle times both paths on the
+// caller's x and keeps the faster one.
+//
+// Environment (read per call; a change rebuilds the plan):  SPAM_SPMV_SLICED 0 never / 1 decide (default) / 2 always;
+// SPAM_SPMV_SLICE_KB table bytes per XCD (3072);  SPAM_SPMV_LDS_KB hottest slots copied to LDS (-1 decide, 0 never);
+// SPAM_SPMV_L0_KB contiguous hottest level without LDS (16);  SPAM_SPMV_LONG rows with at least this many entries go
+// to the slabs (0: from the one-table miss rate);  SPAM_SPMV_SLICED_TPB / _NPT / _WGS kernel geometry;  SPAM_SPMV_PIPE
+// 0 plain loop / 1 pipelined (default);  SPAM_SPMV_PROF 1 in-kernel phase timers, 2 skip phase 2 (diagnostics);
+// plain path: SPAM_SPMV_NPT, SPAM_SPMV_NT, SPAM_SPMV_HOT, SPAM_SPMV_HOT_KB.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
