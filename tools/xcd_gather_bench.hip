@@ -156,6 +156,103 @@ int run2(double slice_mb, int wg_per_cu, int skew_bits) {
   return 0;
 }
 
+
+// Fourth series: whole tiles are either LDS-kind (every index < LDSK, gathered from the workgroup's LDS copy with ds_read:
+// no vector-memory gather at all) or table-kind; `pct` percent of the tiles are LDS-kind.  Workgroup shape and table size vary.
+template <class T, int TPBX, int NPTX, int LDSK>
+__global__ __launch_bounds__(TPBX) void gather3_kernel(const uint32_t* __restrict__ idx, const T* __restrict__ vals,
+                                                       const T* __restrict__ table, T* __restrict__ out, uint32_t tiles_per_slab,
+                                                       uint32_t* __restrict__ heads, uint32_t slice, uint32_t pct) {
+  constexpr int TILEX = TPBX * NPTX;
+  __shared__ uint32_t s_t;
+  __shared__ T prod[TILEX + TILEX / 32 + 1];
+  extern __shared__ __align__(16) unsigned char dyn[];
+  T* ltab = (T*)dyn;
+  const uint32_t xcc = xcc_id() & 7;
+  for (int j = threadIdx.x; j < LDSK; j += TPBX) ltab[j] = table[(uint64_t)xcc * slice + j];
+  typedef T VT __attribute__((ext_vector_type(16 / sizeof(T))));
+  constexpr int VN = 16 / sizeof(T);
+  T acc = 0;
+  for (;;) {
+    if (threadIdx.x == 0) s_t = atomicAdd(&heads[xcc * 64], 1u);
+    __syncthreads();
+    const uint32_t t = s_t;
+    __syncthreads();
+    if (t >= tiles_per_slab) break;
+    const bool lds_tile = (t % 100u) < pct;
+    const uint64_t base = ((uint64_t)xcc * tiles_per_slab + t) * TILEX;
+    u32x4 c[NPTX / 4];
+    VT v[NPTX / 4][4 / VN];
+#pragma unroll
+    for (int i = 0; i < NPTX / 4; ++i) {
+      const uint64_t q = base + (uint64_t)(i * TPBX + threadIdx.x) * 4;
+      c[i] = __builtin_nontemporal_load((const u32x4*)(idx + q));
+#pragma unroll
+      for (int j = 0; j < 4 / VN; ++j) v[i][j] = __builtin_nontemporal_load((const VT*)(vals + q) + j);
+    }
+    T xv[NPTX / 4][4];
+    if (lds_tile) {
+#pragma unroll
+      for (int i = 0; i < NPTX / 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[i][j] = ltab[c[i][j] - xcc * slice];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPTX / 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[i][j] = table[c[i][j]];
+    }
+#pragma unroll
+    for (int i = 0; i < NPTX / 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int q = (i * TPBX + threadIdx.x) * 4 + j; prod[q + (q >> 5)] = v[i][j / VN][j % VN] * xv[i][j]; }
+    __syncthreads();
+    for (int k = 0; k < NPTX; ++k) { const int q = threadIdx.x * NPTX + k; acc += prod[q + (q >> 5)]; }
+  }
+  out[(uint64_t)blockIdx.x * TPBX + threadIdx.x] = acc;
+}
+__global__ void fill_idx3(uint32_t* idx, uint64_t n, uint32_t tiles_per_slab, uint32_t tile, uint64_t slice, uint32_t ldsk, uint32_t pct, uint64_t seed) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t slab = i / ((uint64_t)tiles_per_slab * tile);
+  const uint32_t t = (uint32_t)((i / tile) % tiles_per_slab);
+  const uint64_t h = mix(i + seed);
+  const uint64_t v = (t % 100u) < pct ? h % ldsk : ldsk + h % (slice - ldsk);
+  idx[i] = (uint32_t)(slab * slice + v);
+}
+template <class T, int TPBX, int NPTX, int LDSK>
+int run3(double slice_mb, int wg_per_cu, uint32_t pct) {
+  constexpr int TILEX = TPBX * NPTX;
+  const uint32_t tiles_per_slab = (uint32_t)((1ull << 24) / TILEX);   // 16.8 M gathers per slab, 134 M in all
+  const uint64_t n = (uint64_t)tiles_per_slab * 8 * TILEX;
+  const uint64_t slice = (uint64_t)(slice_mb * 1048576 / sizeof(T));
+  uint32_t *idx, *heads; T *table, *out, *vals;
+  const unsigned grid = 256 * wg_per_cu;
+  CK(hipMalloc(&idx, n * 4)); CK(hipMalloc(&vals, n * sizeof(T))); CK(hipMalloc(&table, slice * 8 * sizeof(T)));
+  CK(hipMalloc(&out, (uint64_t)grid * TPBX * sizeof(T))); CK(hipMalloc(&heads, 8 * 256));
+  CK(hipMemset(table, 0, slice * 8 * sizeof(T))); CK(hipMemset(vals, 0, n * sizeof(T)));
+  fill_idx3<<<(unsigned)((n + 255) / 256), 256>>>(idx, n, tiles_per_slab, TILEX, slice, LDSK, pct, 999);
+  CK(hipDeviceSynchronize());
+  auto kern = gather3_kernel<T, TPBX, NPTX, LDSK>;
+  const size_t dynb = (size_t)LDSK * sizeof(T);
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynb));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  const int reps = 5; float tot = 0;
+  for (int r = -2; r < reps; ++r) {
+    CK(hipMemsetAsync(heads, 0, 8 * 256, 0));
+    CK(hipEventRecord(a));
+    kern<<<grid, TPBX, dynb>>>(idx, vals, table, out, tiles_per_slab, heads, (uint32_t)slice, pct);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float m; CK(hipEventElapsedTime(&m, a, b));
+    if (r >= 0) tot += m;
+  }
+  const float ms = tot / reps;
+  printf("tile kinds: %d threads x %d, %d WG/CU, LDS table %d slots (%zu KB), %u %% LDS tiles: %.3f ms %.1f Ggather/s\n", TPBX, NPTX, wg_per_cu,
+         LDSK, dynb / 1024, pct, ms, n / ms / 1e6);
+  CK(hipFree(idx)); CK(hipFree(vals)); CK(hipFree(table)); CK(hipFree(out)); CK(hipFree(heads));
+  return 0;
+}
+
 __global__ void fill_idx(uint32_t* idx, uint64_t n, uint32_t tiles_per_slab, uint64_t slice, uint64_t seed) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -202,6 +299,16 @@ int run(double slice_mb, int wg_per_cu) {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 3) {  // fourth series: pure-LDS tiles next to table tiles
+    for (uint32_t pct : {0u, 33u, 50u, 60u}) {
+      run3<double, 256, 8, 2048>(2.75, 4, pct);
+      run3<double, 512, 8, 4096>(2.75, 2, pct);
+      run3<double, 512, 8, 8192>(2.75, 1, pct);
+      run3<double, 1024, 8, 8192>(2.75, 1, pct);
+      run3<double, 1024, 8, 12288>(2.75, 1, pct);
+    }
+    return 0;
+  }
   if (argc > 2) {  // third series: a share of the gathers served from a 2048-slot LDS table (skew -P = P percent)
     for (int pct : {0, 30, 50, 70}) {
       run2<double, true, true, 0>(2.75, 3, -pct);
