@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--spgemm-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv", action="store_true")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the informational f32 power-law SpMV line")
     ap.add_argument("--spmv-sharded", action="store_true",
                     help="N > 1: ONE 10 M-row matrix row-sharded over the ranks, x all-gathered every step (strong scaling) "
                          "instead of one matrix per rank (weak scaling, the default)")
@@ -231,6 +232,33 @@ def main():
             del a_host, xh, yh, ref
         del dA, A, x, y
         torch.cuda.empty_cache()
+        # BASELINE configs[4] beside it (rank 0, N = 1 only; informational, never `value`): 2 M rows, 0.1 % of them with
+        # 50 000 entries, f32 — the row-bin / long-row stress case, same timing method
+        if rank == 0 and world == 1 and not args.no_cfg5:
+            A5 = synth.powerlaw(dtype=torch.float32, device=dev)
+            x5 = synth.dense_vector(A5.cols, dtype=torch.float32, device=dev)
+            y5 = torch.empty(A5.rows, dtype=torch.float32, device=dev)
+            d5 = DeviceCsr.from_torch(A5.rows, A5.cols, A5.row_ptr, A5.col_idx, A5.vals, True)
+            for _ in range(args.warmup):
+                d5.spmv_dev(x5.data_ptr(), y5.data_ptr())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.steps):
+                d5.spmv_dev(x5.data_ptr(), y5.data_ptr())
+            e1.record()
+            torch.cuda.synchronize()
+            ms5 = e0.elapsed_time(e1) / args.steps
+            b5 = spmv_alg_bytes(A5.rows, A5.cols, A5.nnz, 4)
+            out["spmv_powerlaw_f32"] = {"workload": "csr_spmv_f32_powerlaw_2Mx2M (BASELINE configs[4])", "rows": A5.rows,
+                                        "nnz": A5.nnz, "max_nnz_row": A5.stats()["max_nnz_row"], "ms_per_step": round(ms5, 4),
+                                        "effective_GB_per_s": round(b5 / (ms5 * 1e-3) / 1e9, 1),
+                                        "frac_of_hbm_peak": round(b5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                        "algorithmic_bytes": b5,
+                                        "plan": "xcd_sliced" if d5.spmv_plan_info()["sliced"]["active"] else "plain"}
+            log(f"[spmv f32 power-law] {ms5:.4f} ms/step, {b5 / (ms5 * 1e-3) / 1e9:.0f} GB/s")
+            del d5, A5, x5, y5
+            torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ SpGEMM (secondary) ---------
     scale = args.spgemm_scale

@@ -8,7 +8,7 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum" "TCP_TCC_READ_REQ_sum"; do
   name=$(echo $grp | tr ' ' '_')
-  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --spgemm-scale 0 > /dev/null 2> $OUT/pmc_$name.log || echo "pmc $grp failed" >> $OUT/errors.log
+  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-cfg5 --spgemm-scale 0 > /dev/null 2> $OUT/pmc_$name.log || echo "pmc $grp failed" >> $OUT/errors.log
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
