@@ -124,13 +124,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int pad_idx(int i) { return i + (i >> 5); }
 
-template <class T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
-
 // Sum over the wavefront through DPP moves (no LDS crossbar traffic, ~10x less latency than six ds_bpermute
 // rounds for a double); the total arrives in lane 63 only.  Lanes without a source lane add 0.
 template <int CTRL, int ROW_MASK, class T>
@@ -707,7 +700,6 @@ struct SlabDesc {
 };
 
 struct SlicedPlan {
-  int mode_built = 0;           // the configuration key this plan was built for
   uint32_t S = 0, L = 0;        // table slots per slab; the first L hold the most referenced columns, contiguous (they
                                 // stay in the CU's 32 KB L1; with use_lds every workgroup copies them to LDS instead)
   bool use_lds = false;
@@ -783,7 +775,7 @@ struct GatherSliced {
 // the slab table in the local L2, the hottest L slots in LDS), and afterwards helps the other slabs finish.
 template <class T, int TPB, int NPT, bool LDS, int PROF = 0>
 __global__ __launch_bounds__(TPB) void spmv_sliced_kernel(const SlabDesc<T>* __restrict__ descs, const T* __restrict__ x,
-                                                         uint32_t S, uint32_t L, uint32_t* __restrict__ heads) {
+                                                         uint32_t L, uint32_t* __restrict__ heads) {
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   __shared__ TileSmem<T, TPB, NPT> sm;
   __shared__ uint32_t s_t;
@@ -827,7 +819,7 @@ __global__ __launch_bounds__(TPB) void spmv_sliced_kernel(const SlabDesc<T>* __r
 // per tile leave the L2 request queues a third empty: 175 instead of 230 G gathers/s).  Tickets are drawn two ahead.
 template <class T, int TPB, int NPT, bool LDS, int PROF = 0>
 __global__ __launch_bounds__(TPB) void spmv_sliced_pipe_kernel(const SlabDesc<T>* __restrict__ descs, const T* __restrict__ x,
-                                                              uint32_t S, uint32_t L, uint32_t* __restrict__ heads) {
+                                                              uint32_t L, uint32_t* __restrict__ heads) {
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   __shared__ TileSmem<T, TPB, NPT> sm;
   __shared__ uint32_t s_t[2];
@@ -992,7 +984,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t v) {
 // another.  Everything else is cold: part NSLAB, gathered from x itself.
 __global__ void sliced_assign_kernel(const uint32_t* __restrict__ f0, const uint32_t* __restrict__ f1,
                                      const uint64_t* __restrict__ p0, const uint64_t* __restrict__ p1, uint32_t cols,
-                                     uint32_t L, uint32_t S, uint32_t line_slots, uint32_t* __restrict__ code,
+                                     uint32_t L, uint32_t S, uint32_t* __restrict__ code,
                                      uint8_t* __restrict__ slab, uint32_t* __restrict__ dest) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cols) return;
@@ -1127,7 +1119,7 @@ static int sliced_launch_variant(const SlicedPlan* q, const T* x, hipStream_t s,
   if (prof == 1 && q->pipelined) {
     unsigned long long h[8] = {0};
     SPAM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_prof), h, sizeof(h)));
-    kern<<<q->grid, TPB, dyn, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+    kern<<<q->grid, TPB, dyn, s>>>((const SlabDesc<T>*)q->descs, x, q->L, q->heads);
     SPAM_CHECK_LAUNCH();
     SPAM_HIP_TRY(hipStreamSynchronize(s));
     SPAM_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_spmv_prof), sizeof(h)));
@@ -1152,7 +1144,7 @@ static int sliced_launch_variant(const SlicedPlan* q, const T* x, hipStream_t s,
     *grid_out = (unsigned)g;
     return SPAM_OK;
   }
-  kern<<<q->grid, TPB, dyn, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+  kern<<<q->grid, TPB, dyn, s>>>((const SlabDesc<T>*)q->descs, x, q->L, q->heads);
   SPAM_CHECK_LAUNCH();
   return SPAM_OK;
 }
@@ -1162,14 +1154,14 @@ static int sliced_dispatch(const SlicedPlan* q, const T* x, hipStream_t s, unsig
   if (!grid_out && q->tpb == 256 && q->npt == 16 && !q->use_lds && !q->pipelined) {
     const int prof = env_int("SPAM_SPMV_PROF", 0);
     if (prof == 2) {  // experiment: phase 1 only (wrong results)
-      spmv_sliced_kernel<T, 256, 16, false, 2><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+      spmv_sliced_kernel<T, 256, 16, false, 2><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->L, q->heads);
       SPAM_CHECK_LAUNCH();
       return SPAM_OK;
     }
     if (prof == 1) {
       unsigned long long h[8] = {0};
       SPAM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_prof), h, sizeof(h)));
-      spmv_sliced_kernel<T, 256, 16, false, 1><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->S, q->L, q->heads);
+      spmv_sliced_kernel<T, 256, 16, false, 1><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->L, q->heads);
       SPAM_CHECK_LAUNCH();
       SPAM_HIP_TRY(hipStreamSynchronize(s));
       SPAM_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_spmv_prof), sizeof(h)));
@@ -1273,7 +1265,7 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
   SPAM_TRY(scan_u32_to_u64(f0.as<uint32_t>(), cols, p0.as<uint64_t>(), tmp.p, s));
   SPAM_TRY(scan_u32_to_u64(f1.as<uint32_t>(), cols, p1.as<uint64_t>(), tmp.p, s));
   sliced_assign_kernel<<<gc, 256, 0, s>>>(f0.as<uint32_t>(), f1.as<uint32_t>(), p0.as<uint64_t>(), p1.as<uint64_t>(), cols, L, S,
-                                          line_slots, code.as<uint32_t>(), slab.as<uint8_t>(), dest.as<uint32_t>());
+                                          code.as<uint32_t>(), slab.as<uint8_t>(), dest.as<uint32_t>());
   SPAM_CHECK_LAUNCH();
 
   // -- rows: long / short ----------------------------------------------------------------------------------
