@@ -33,13 +33,14 @@
 namespace spam {
 
 // ---- geometry -------------------------------------------------------------------------------------
-// numeric chunk width of the heavy path: 2^14 columns with 1024-thread workgroups (157 KB of LDS, one per CU).  The
-// 2^13 / 512-thread geometry (80 KB, two per CU) exists for A/B runs (SPAM_HEAVY_TPB=512): it doubles the number of
-// chunk groups and measured 10 % slower on R-MAT scale 20 (225 vs 203 ms numeric).
-constexpr int CW_SHIFT_SMALL = 13, CW_SHIFT_LARGE = 14;
-constexpr uint32_t MAXCH_SMALL = 512, MAXCH_LARGE = 1024;  // chunks per row the LDS group list can hold
+// numeric chunk width of the heavy path = 16 columns per thread of the workgroup: 2^13 columns with 512 threads
+// (72 KB of LDS: two workgroups per CU, one drains while the other multiplies — the default), 2^14 with 1024 threads
+// (144 KB, one per CU: used for very wide B, where it halves the B-split table) and 2^12 with 256 (36 KB, four per CU).
+// SPAM_HEAVY_TPB = 256 / 512 / 1024 forces one (A/B runs).
+constexpr int CW_SHIFT_256 = 12, CW_SHIFT_512 = 13, CW_SHIFT_1024 = 14;
+constexpr uint64_t WIDE_B_CHUNKS = 8192;        // more 2^13-column chunks than this: use the 2^14 geometry
 
-constexpr uint32_t HEAVY_GRID = 8192;           // persistent workgroups of the heavy kernels (1 fits per CU)
+constexpr uint32_t HEAVY_GRID = 8192;           // persistent workgroups of the symbolic heavy kernels (1 fits per CU)
 
 constexpr int NSYM = 4;                         // symbolic bins by F
 constexpr uint64_t SYM_MAX[NSYM - 1] = {64, 512, 4096};
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ 
 // Symbolic pass for heavy rows: one workgroup per row, a 2^20-column bitmap window in LDS (LDS atomic OR),
 // then a popcount per numeric chunk.  The row's k list stays in LDS across windows when it fits.
 constexpr int BM_WORDS = 32768;                  // 128 KB bitmap = 2^20 columns = 64 numeric chunks per window
-constexpr int BM_CHUNKS_MAX = (BM_WORDS * 32) >> CW_SHIFT_SMALL;  // 128 chunks per window at most
+constexpr int BM_CHUNKS_MAX = (BM_WORDS * 32) >> CW_SHIFT_256;  // 256 chunks per window at most
 constexpr int BM_SHIFT = 20;
 
 template <bool USE_BPOS>
@@ -743,37 +744,6 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void num_hash_kernel(
   }
 }
 
-// rows whose A row is longer than `thr` go to the giant list (processed as several items per row)
-__global__ __launch_bounds__(256) void split_giant_kernel(const uint32_t* __restrict__ list, uint32_t n,
-                                                         const uint64_t* __restrict__ a_rp, uint32_t thr,
-                                                         uint32_t* __restrict__ normal, uint32_t* __restrict__ giant,
-                                                         uint32_t* __restrict__ counts) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  uint32_t r = 0;
-  bool valid = i < n, g = false;
-  if (valid) {
-    r = list[i];
-    g = a_rp[r + 1] - a_rp[r] > thr;
-  }
-  // one atomic per wavefront and class, lanes ranked by ballot
-  const uint64_t mg = __ballot(valid && g), mn = __ballot(valid && !g);
-  uint32_t bg = 0, bn = 0;
-  if (lane == 0) {
-    if (mg) bg = atomicAdd(&counts[1], (uint32_t)__popcll(mg));
-    if (mn) bn = atomicAdd(&counts[0], (uint32_t)__popcll(mn));
-  }
-  bg = __shfl(bg, 0, 64);
-  bn = __shfl(bn, 0, 64);
-  if (valid) {
-    const uint64_t below = (1ull << lane) - 1;
-    if (g)
-      giant[bg + __popcll(mg & below)] = r;
-    else
-      normal[bn + __popcll(mn & below)] = r;
-  }
-}
-
 // Longest-first order for the work queues: rows are bucketed by floor(log2(F)) (64 buckets, heaviest bucket
 // first; order inside a bucket is unspecified).  A queue that ends on small rows has a short tail.
 __global__ __launch_bounds__(256) void cost_hist_kernel(const uint32_t* __restrict__ list, uint32_t n,
@@ -815,8 +785,286 @@ __global__ __launch_bounds__(256) void cost_scatter_kernel(const uint32_t* __res
   if (i < n) out[base[b] + rank] = r;
 }
 
-// Numeric pass for heavy rows: one workgroup per row.  The row's numeric chunks are grouped on the fly:
-//   * a chunk holding more than HWIN entries (>12 % dense) is accumulated DENSELY: T acc[CW] + byte flags,
+// ---- wave-autonomous product streaming (heavy numeric path) --------------------------------------------------
+// One wavefront owns up to 64 entries k of A's row — one per lane, kept in registers: the position range
+// [lo, lo + len) of B's row k that falls into the current chunk group and the value a.  The lengths are prefix-summed
+// across the wave with DPP moves (no LDS) and the wave walks the concatenated product index space 64 * U products per
+// round, lane-contiguous inside every load instruction whatever the mix of short and long segments.  The segment of a
+// product index is found by a search over the lanes' start offsets: two ballots bound the segments a 64-product window
+// touches (a scalar range), the bisection inside that range costs ceil(log2(range + 1)) ds_bpermute rounds — zero when
+// the window lies in one segment.  Nothing here synchronises with other wavefronts, so the 16 wavefronts of a
+// workgroup run out of phase and their global-load latencies overlap; the workgroup meets only at group boundaries.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive prefix sum over the 64 lanes (Hillis-Steele inside the 16-lane rows, then the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += dpp_u32<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_u32<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_u32<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_u32<0x118, 0xF>(v);  // row_shr:8
+  v += dpp_u32<0x142, 0xA>(v);  // row_bcast:15 -> rows 1 and 3
+  v += dpp_u32<0x143, 0xC>(v);  // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint32_t shfl_u32(uint32_t v, uint32_t src_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+__device__ __forceinline__ double shfl_val(double v, uint32_t src_lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const uint32_t lo = shfl_u32((uint32_t)b, src_lane), hi = shfl_u32((uint32_t)(b >> 32), src_lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+__device__ __forceinline__ float shfl_val(float v, uint32_t src_lane) {
+  return __builtin_bit_cast(float, shfl_u32(__builtin_bit_cast(uint32_t, v), src_lane));
+}
+
+#ifndef SPAM_WAVE_U
+#define SPAM_WAVE_U 4
+#endif
+#ifndef SPAM_HEAVY_PROBE
+#define SPAM_HEAVY_PROBE 0  // 0: linear probing, one key after the other; 1: double hashing, all keys of a round in lockstep
+#endif
+constexpr int WAVE_U = SPAM_WAVE_U;  // products per lane and round: that many independent (col, val) loads in flight per lane
+
+// sum over the 64 lanes through DPP moves (no LDS traffic); the total is returned in every lane
+__device__ __forceinline__ uint32_t wave_total_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
+}
+
+// U upserts per lane into the group's table, all lanes and all U keys probing in lockstep: every pass issues the
+// pending CAS of all U keys back to back (one LDS round trip per pass whatever U is), then the adds of the keys that
+// found their slot.  Double hashing (odd step from a second multiplicative hash): the longest probe sequence among
+// the 64 x U keys of a pass sets the number of passes, and linear probing's clusters make that tail several times
+// longer at load 0.5 - 0.75.  The slot order this produces is this library's own "table order" (sort_rows = 0).
+template <class T, int U>
+__device__ __forceinline__ void lds_map_upsert_rounds(uint32_t* keys, T* vals, uint32_t mask, const uint32_t (&k)[U],
+                                                      const T (&v)[U], const bool (&ok)[U]) {
+  uint32_t h[U], step[U], old[U];
+  bool pend[U];
+  const int sh = __clz(mask);
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    h[j] = ((k[j] * 0x9E3779B1u) >> sh) & mask;
+    step[j] = ((k[j] * 0x85EBCA6Bu) >> 23) | 1u;
+    pend[j] = ok[j];
+    old[j] = 0;
+  }
+  for (;;) {
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+      if (pend[j]) old[j] = atomicCAS(&keys[h[j]], EMPTY_KEY, k[j]);
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (pend[j]) {
+        if (old[j] == EMPTY_KEY || old[j] == k[j]) {
+          lds_add(&vals[h[j]], v[j]);
+          pend[j] = false;
+        } else {
+          h[j] = (h[j] + step[j]) & mask;
+          any = true;
+        }
+      }
+    }
+    if (!__any(any)) break;
+  }
+}
+
+// One round of WAVE_U accumulations per lane.  acc / flags: dense accumulator over the group's column window;
+// hkeys / hvals: the group's hash table.
+template <class T, uint32_t HMASK>
+__device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[WAVE_U], const T (&prods)[WAVE_U], uint32_t c0,
+                                                 uint32_t cspan, bool dense, T* acc, uint8_t* flags, uint32_t* hkeys,
+                                                 T* hvals) {
+  bool okv[WAVE_U];
+#pragma unroll
+  for (int j = 0; j < WAVE_U; ++j) okv[j] = cols[j] != EMPTY_KEY && (cols[j] - c0) < cspan;
+  if (dense) {  // (uniform)
+#pragma unroll
+    for (int j = 0; j < WAVE_U; ++j) {
+      if (okv[j]) {
+        const uint32_t c = cols[j] - c0;
+        lds_add(&acc[c], prods[j]);
+        flags[c] = 1;
+      }
+    }
+  } else {
+#if SPAM_HEAVY_PROBE
+    lds_map_upsert_rounds<T, WAVE_U>(hkeys, hvals, HMASK, cols, prods, okv);
+#else
+    lds_map_upsert_batch<T, WAVE_U, true>(hkeys, hvals, HMASK, cols, prods, okv);
+#endif
+  }
+}
+
+// Long segments (>= LONG_SEG products) are cut into 64-product PIECES whose parameters are scalars (v_readlane of
+// the owning lane's registers): a piece is one coalesced load of columns and one of values at SGPR base + lane,
+// no segment search, no shuffles.  `deal` = NW for the shared entries every wavefront holds (piece p of segment s goes
+// to wavefront (s + p) mod NW, so a hub's products spread evenly over the workgroup) and 1 for entries this
+// wavefront owns alone.  WAVE_U pieces are gathered per round so that their loads are in flight together.
+constexpr uint32_t LONG_SEG = 64;
+
+template <class T, uint32_t HMASK>
+__device__ __forceinline__ void long_pieces(uint64_t lmask, uint32_t lo, uint32_t len, T av, uint32_t deal, uint32_t wave,
+                                            const uint32_t* __restrict__ b_col, const T* __restrict__ b_val, uint32_t c0,
+                                            uint32_t cspan, bool dense, T* acc, uint8_t* flags, uint32_t* hkeys, T* hvals) {
+  const uint32_t lane = threadIdx.x & 63;
+  // scalar piece iterator
+  uint64_t m = lmask;
+  uint32_t s_lo = 0, s_len = 0, p = 0, np = 0;
+  T s_a = T(0);
+  auto next_piece = [&]() -> bool {  // advances (s_lo, s_len, s_a, p) to this wavefront's next piece; false when done
+    for (;;) {
+      if (p < np) return true;
+      if (!m) return false;
+      const uint32_t sidx = (uint32_t)__builtin_ctzll(m);
+      m &= m - 1;
+      s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)sidx);
+      s_len = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)sidx);
+      if constexpr (sizeof(T) == 8) {
+        const long long b = __builtin_bit_cast(long long, av);
+        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, (int)sidx);
+        const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), (int)sidx);
+        s_a = __builtin_bit_cast(T, ((long long)h0 << 32) | (long long)l0);
+      } else {
+        s_a = __builtin_bit_cast(T, (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, av), (int)sidx));
+      }
+      np = (s_len + 63) >> 6;
+      p = deal > 1 ? (wave + deal - (sidx % deal)) % deal : 0u;
+    }
+  };
+  bool more = next_piece();
+  while (more) {
+    uint32_t cols[WAVE_U];
+    T prods[WAVE_U], bv[WAVE_U], aa[WAVE_U];
+#pragma unroll
+    for (int j = 0; j < WAVE_U; ++j) {
+      cols[j] = EMPTY_KEY;
+      bv[j] = T(0), aa[j] = T(0);
+      if (more) {  // (uniform)
+        const uint32_t idx = p * 64 + lane;
+        if (idx < s_len) {
+          cols[j] = b_col[(uint64_t)s_lo + idx];
+          bv[j] = b_val[(uint64_t)s_lo + idx];
+        }
+        aa[j] = s_a;
+        p += deal;
+        more = next_piece();
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WAVE_U; ++j) prods[j] = aa[j] * bv[j];  // t * t1 (mul_hash.rs:154)
+    accumulate_round<T, HMASK>(cols, prods, c0, cspan, dense, acc, flags, hkeys, hvals);
+  }
+}
+
+// The products of one wavefront's 64 segments (one per lane: positions [lo, lo + len) of B's arrays, value av).
+// shared = true: every wavefront of the workgroup holds the same 64 segments (the head of A's row): long ones are
+// dealt piecewise, a short one goes whole to wavefront lane mod NW.  shared = false: the segments are this wavefront's own.
+// Short segments are walked through the flattened product index space: the lengths are prefix-summed across the wave
+// with DPP moves and the wave takes 64 * WAVE_U consecutive products per round, lane-contiguous inside every load.
+template <class T, uint32_t HMASK>
+__device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, bool shared, uint32_t nw, uint32_t wave,
+                                              const uint32_t* __restrict__ b_col,
+                                              const T* __restrict__ b_val, uint32_t c0, uint32_t cspan, bool dense,
+                                              T* acc, uint8_t* flags, uint32_t* hkeys, T* hvals,
+                                              unsigned long long* stat = nullptr /* SPAM_DBG_HEAVY=32: thread 0's timers */) {
+  const uint32_t lane = threadIdx.x & 63;
+  unsigned long long q0 = 0, q1 = 0, q2 = 0;
+  if (stat) q0 = clock64();
+  const uint64_t lmask = __ballot(len >= LONG_SEG);
+  if (lmask) long_pieces<T, HMASK>(lmask, lo, len, av, shared ? nw : 1u, wave, b_col, b_val, c0, cspan, dense, acc, flags, hkeys, hvals);
+  if (len >= LONG_SEG || (shared && (lane % nw) != wave)) len = 0;
+  if (stat) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stat[4] += clock64() - q0;
+  }
+  const uint32_t inc = wave_incl_scan_u32(len);
+  const uint32_t st = inc - len;                         // first product index of this lane's segment
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+  const uint32_t off = lo - st;                          // q = off[s] + idx for a product index idx of segment s
+  for (uint32_t base = 0; base < total; base += 64 * WAVE_U) {
+    if (stat) q0 = clock64();
+    // segment search for the WAVE_U windows of this round in lockstep.  st is non-decreasing over the lanes: the lanes
+    // with st <= w form a prefix whose last member is the segment holding product w (empty segments share their
+    // successor's start and are skipped by taking the last), so two ballots bound the segments a 64-product window
+    // touches; the bisection inside [slo, shi] runs for all windows at once, one ds_bpermute round trip per halving.
+    uint32_t slo[WAVE_U], shi[WAVE_U];
+    uint32_t maxspan = 0;
+#pragma unroll
+    for (int j = 0; j < WAVE_U; ++j) {
+      const uint32_t w0 = base + 64 * j;                 // uniform
+      slo[j] = 0, shi[j] = 0;
+      if (w0 < total) {
+        const uint32_t w1 = (w0 + 63 < total ? w0 + 63 : total - 1);
+        const uint32_t a0 = (uint32_t)__popcll(__ballot(st <= w0)) - 1u;
+        const uint32_t a1 = (uint32_t)__popcll(__ballot(st <= w1)) - 1u;
+        slo[j] = a0, shi[j] = a1;
+        maxspan = a1 - a0 > maxspan ? a1 - a0 : maxspan;
+      }
+    }
+#ifdef SPAM_ABLATE_SEARCH
+    maxspan = 0;
+#endif
+    for (uint32_t span = maxspan; span != 0; span >>= 1) {  // uniform trip count
+      uint32_t v[WAVE_U], mid[WAVE_U];
+#pragma unroll
+      for (int j = 0; j < WAVE_U; ++j) {
+        mid[j] = (slo[j] + shi[j] + 1) >> 1;
+        v[j] = shfl_u32(st, mid[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < WAVE_U; ++j) {
+        const uint32_t idx = base + 64 * j + lane;
+        if (v[j] <= idx)
+          slo[j] = mid[j];                               // (mid == slo when the range is a single segment: no change)
+        else
+          shi[j] = mid[j] - 1;
+      }
+    }
+    uint32_t cols[WAVE_U], qq[WAVE_U];
+    T bv[WAVE_U];
+#pragma unroll
+    for (int j = 0; j < WAVE_U; ++j) qq[j] = shfl_u32(off, slo[j]);
+#pragma unroll
+    for (int j = 0; j < WAVE_U; ++j) {
+      const uint32_t idx = base + 64 * j + lane;
+      cols[j] = EMPTY_KEY;
+      bv[j] = T(0);
+      if (idx < total) {
+#ifdef SPAM_ABLATE_LOADS
+        cols[j] = c0 + ((qq[j] + idx) * 2654435761u) % cspan;
+        bv[j] = T(1);
+#else
+        cols[j] = b_col[qq[j] + idx];
+        bv[j] = b_val[qq[j] + idx];
+#endif
+      }
+    }
+    T aa[WAVE_U];
+#pragma unroll
+    for (int j = 0; j < WAVE_U; ++j) aa[j] = shfl_val(av, slo[j]);
+    if (stat) {
+      q1 = clock64();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      q2 = clock64();
+    }
+    T prods[WAVE_U];
+#pragma unroll
+    for (int j = 0; j < WAVE_U; ++j) prods[j] = aa[j] * bv[j];  // t * t1 (mul_hash.rs:154)
+    accumulate_round<T, HMASK>(cols, prods, c0, cspan, dense, acc, flags, hkeys, hvals);
+    if (stat) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long q3 = clock64();
+      stat[0] += q1 - q0, stat[1] += q2 - q1, stat[2] += q3 - q2, stat[3] += 1;
+    }
+  }
+}
+
+// Numeric pass for heavy rows.  A row's numeric chunks are grouped (heavy_groups_kernel):
+//   * a chunk holding more than HWIN entries (>19 % dense) is accumulated DENSELY: T acc[CW] + byte flags,
 //     LDS float atomics, compaction in column order;
 //   * runs of sparser chunks are merged while their entries stay below HCAP and share one linprobe table
 //     of HTSIZE slots laid over the same LDS (keys u32 + values T), compaction in slot order.
@@ -824,313 +1072,397 @@ __global__ __launch_bounds__(256) void cost_scatter_kernel(const uint32_t* __res
 // column order, and every touched LDS slot is reset while it is read out.
 //   HTSIZE = CW/2 slots;  HCAP = load * HTSIZE: a hash group holds fewer entries;  HWIN = HCAP/2: grouping
 //   window / dense threshold.
+// Every (row, group) is a work item of its own, and the items are queued in COLUMN-WINDOW order (all groups starting
+// in chunk 0, then chunk 1, ...; dense before hash inside a chunk).  At any moment the workgroups of the whole chip
+// therefore read the same 1/nchunks slice of B — a few MB that stay in every XCD's L2 — instead of all of B (200 MB
+// at scale 20: 63 % of the L2 lookups missed when every workgroup walked its own row's groups).  Giant A rows need no
+// special casing: their groups are independent items like everyone else's.
+// Workgroups take items in runs of ITEM_RUN consecutive queue positions (one atomic per run) and prefetch across
+// items: while item i is multiplied, the B-split lookups of item i + 1 and the A entries of item i + 2 are in flight.
+// Inside an item the wavefronts stream products on their own (wave_products); the workgroup synchronises three times:
+// products done -> per-wave entry counts -> LDS drained and clean.  A rows of at most TPB entries sit in registers —
+// thread (wave w, lane l) owns entry l * NW + w, so every wavefront gets an even sample of the (sorted) row; longer A
+// rows are streamed in 64-entry batches per wavefront with the same two-stage prefetch.
+// The drain is per wavefront over a contiguous slice of the accumulator: 64 consecutive slots per step, ranked by
+// ballot, so LDS reads are conflict-free and the stores to C coalesce.
 constexpr uint32_t HEAVY_LOAD_16THS = 12;  // max load factor of a heavy hash group in sixteenths (12 = 0.75)
-constexpr uint32_t GIANT_NNZ_A = 1024;  // A rows longer than this are cut into GIANT_PARTS work items
-constexpr uint32_t GIANT_PARTS = 16;
+constexpr uint32_t ITEM_RUN = 8;           // queue positions a workgroup claims per atomic
+constexpr uint32_t ITEM_DENSE = 0x80000000u;
+
+struct HeavyItem {       // 32 bytes, read with scalar loads
+  uint64_t a_start;      // first entry of A's row
+  uint64_t out;          // where the group's piece of C's row starts
+  uint32_t n_a;          // entries of A's row
+  uint32_t j0;           // chunk range [j0, j1) of the group
+  uint32_t j1_kind;      // j1 | ITEM_DENSE
+  uint32_t cnt;          // entries of C the group produces (> 0)
+};
+
+// One wavefront per heavy row: cut the row's chunks into groups and emit one item per non-empty group.  A chunk with
+// more than `hwin` entries is a dense group of its own; the chunks between two dense ones are merged greedily, left to
+// right, while a group stays within `hcap` entries (the hash table's load limit).  The wavefront loads 64 chunk counts
+// at a time; the greedy walk itself is scalar (v_readlane), a few instructions per chunk.
+// FILL = false: count items per queue bucket (hist[2 * j0 + kind]) and the census; FILL = true: write them (cursor =
+// exclusive prefix of hist).
+template <bool FILL>
+__global__ __launch_bounds__(256) void heavy_groups_kernel(const uint32_t* __restrict__ rows_list, uint32_t n_rows,
+                                                          const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks,
+                                                          const uint32_t* __restrict__ hcnt,
+                                                          const uint32_t* __restrict__ hoff,
+                                                          const uint64_t* __restrict__ a_rp,
+                                                          const uint64_t* __restrict__ c_rp, uint32_t hwin, uint32_t hcap,
+                                                          uint32_t* __restrict__ hist_or_cursor,
+                                                          HeavyItem* __restrict__ items,
+                                                          unsigned long long* __restrict__ census) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= n_rows) return;
+  const uint32_t row = rows_list[w];
+  const uint32_t* hc = hcnt + (uint64_t)hrow_of_row[row] * nchunks;
+  const uint32_t* ho = hoff + (uint64_t)hrow_of_row[row] * nchunks;
+  const uint64_t a_start = a_rp[row], out_row = c_rp[row];
+  const uint32_t n_a = (uint32_t)(a_rp[row + 1] - a_start);
+  unsigned long long nd = 0, nh = 0, ed = 0, eh = 0;
+  auto emit = [&](uint32_t j0, uint32_t j1, uint32_t off0, uint32_t cnt, bool dense) {  // lane 0 only
+    const uint32_t key = 2 * j0 + (dense ? 0u : 1u);
+    if (FILL) {
+      const uint32_t pos = atomicAdd(&hist_or_cursor[key], 1u);
+      HeavyItem it;
+      it.a_start = a_start, it.out = out_row + off0, it.n_a = n_a, it.j0 = j0;
+      it.j1_kind = j1 | (dense ? ITEM_DENSE : 0u), it.cnt = cnt;
+      items[pos] = it;
+    } else {
+      atomicAdd(&hist_or_cursor[key], 1u);
+      if (dense)
+        nd += 1, ed += cnt;
+      else
+        nh += 1, eh += cnt;
+    }
+  };
+  uint32_t g_start = 0, g_off = 0, g_cnt = 0;  // the open hash group (uniform)
+  for (uint32_t base = 0; base < nchunks; base += 64) {
+    const uint32_t j = base + lane;
+    const uint32_t c_l = j < nchunks ? hc[j] : 0u, o_l = j < nchunks ? ho[j] : 0u;
+    const uint32_t nb = nchunks - base < 64 ? nchunks - base : 64;
+    for (uint32_t t = 0; t < nb; ++t) {
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)c_l, (int)t);
+      if (c == 0) continue;
+      const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)o_l, (int)t);
+      const uint32_t jj = base + t;
+      if (c > hwin) {  // dense chunk: close the open group, emit the chunk on its own
+        if (g_cnt && lane == 0) emit(g_start, jj, g_off, g_cnt, false);
+        g_cnt = 0;
+        if (lane == 0) emit(jj, jj + 1, o, c, true);
+      } else {
+        if (g_cnt && g_cnt + c > hcap) {
+          if (lane == 0) emit(g_start, jj, g_off, g_cnt, false);
+          g_cnt = 0;
+        }
+        if (g_cnt == 0) g_start = jj, g_off = o;
+        g_cnt += c;
+      }
+    }
+  }
+  if (g_cnt && lane == 0) emit(g_start, nchunks, g_off, g_cnt, false);
+  if (!FILL && lane == 0) {
+    if (nd) atomicAdd(&census[0], nd), atomicAdd(&census[2], ed);
+    if (nh) atomicAdd(&census[1], nh), atomicAdd(&census[3], eh);
+  }
+}
 
 template <class T, bool USE_BPOS, bool SORT, int TPB, int CWS>
-__global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD: two 512-thread workgroups can share a CU
-    const uint64_t* __restrict__ a_rp, const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
-    const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col, const T* __restrict__ b_val,
-    const uint32_t* __restrict__ bpos, uint32_t rows_b, const uint32_t* __restrict__ rows_list, uint32_t n_rows,
-    uint32_t parts, uint32_t* __restrict__ queue, const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks,
-    const uint32_t* __restrict__ hcnt, const uint32_t* __restrict__ hoff, const uint32_t* __restrict__ row_nnz,
-    const uint64_t* __restrict__ c_rp, uint32_t* __restrict__ c_col, T* __restrict__ c_val,
-    unsigned long long* __restrict__ gstats, int dbg) {
-  constexpr int SEG = TPB / 4;
+__global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD: 16 wavefronts per CU whatever TPB is
+    const uint32_t* __restrict__ a_col, const T* __restrict__ a_val, const uint64_t* __restrict__ b_rp,
+    const uint32_t* __restrict__ b_col, const T* __restrict__ b_val, const uint32_t* __restrict__ bpos, uint32_t rows_b,
+    const HeavyItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue, uint32_t* __restrict__ c_col,
+    T* __restrict__ c_val, unsigned long long* __restrict__ gstats, int dbg) {
+  constexpr int NW = TPB / 64;
   constexpr int CW_SHIFT = CWS;
-  constexpr uint32_t CW = 1u << CWS, HTSIZE = CW / 2, HWIN = HEAVY_LOAD_16THS * HTSIZE / 32, HCAP = 2 * HWIN;
-  constexpr uint32_t MAX_HEAVY_CHUNKS = TPB > 512 ? MAXCH_LARGE : MAXCH_SMALL;
-  static_assert(CW == 16 * TPB, "one thread drains 16 consecutive columns");
+  constexpr uint32_t CW = 1u << CWS, HTSIZE = CW / 2;
+  constexpr uint32_t DCOLS = CW / NW;      // dense columns drained per wavefront
+  constexpr uint32_t HSLOTS = HTSIZE / NW;  // hash slots drained per wavefront
+  static_assert(CW == 16 * TPB && DCOLS == 1024 && HSLOTS == 512, "drain geometry: 16 flag bytes / 8 keys per lane");
   __shared__ __attribute__((aligned(16))) T acc[CW];
   __shared__ __attribute__((aligned(16))) uint8_t flags[CW];
-  __shared__ uint32_t seg_start[SEG + 1];
-  __shared__ uint32_t seg_lo[SEG];
-  __shared__ T seg_av[SEG];
-  __shared__ uint32_t klist[SEG];
-  __shared__ T kval[SEG];
-  __shared__ uint32_t wsum[TPB / 64 + 1];
-  __shared__ uint16_t gbeg[MAX_HEAVY_CHUNKS + 1];
-  __shared__ uint32_t goff[MAX_HEAVY_CHUNKS + 1];
-  __shared__ uint32_t ng_s, item_s;
+  __shared__ uint32_t wsum[NW + 1];
+  __shared__ uint32_t run_s;
   static_assert(sizeof(T) * CW >= HTSIZE * (4 + sizeof(T)), "hash table must fit the dense accumulator's LDS");
-  static_assert(HCAP <= HTSIZE * 13 / 16, "a group of non-dense chunks sharing a window holds < HCAP entries");
   uint32_t* hkeys = (uint32_t*)acc;
   T* hvals = (T*)((char*)acc + HTSIZE * 4);
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4* f4 = (u32x4*)flags;
   u32x4* a4 = (u32x4*)acc;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // phase timers of this workgroup (thread 0 only, SPAM_DBG_HEAVY=32), cycles: [0] prefetch issue, [1..4] wave 0's product
+  // rounds: search + load issue, load wait, upserts, number of rounds; [5] wait at the products barrier, [6] drain count +
+  // barrier, [7] drain, [8] closing barrier, [9] items
+  __shared__ unsigned long long wg_stat[11];
+  if (threadIdx.x < 11) wg_stat[threadIdx.x] = 0;
+  unsigned long long t0 = 0;
+  const bool timing = (dbg & 32) && threadIdx.x == 0;
   f4[threadIdx.x] = (u32x4)(0u);  // TPB x 16 = CW flags
   for (int i = threadIdx.x; i < (int)(sizeof(T) * CW / 16); i += TPB) a4[i] = (u32x4)(0u);
-  int mode = 0;  // 0: acc region all zero (dense-clean); 1: hkeys all EMPTY, hvals zero (hash-clean)
+  if (threadIdx.x == 0) run_s = atomicAdd(queue, ITEM_RUN);
   __syncthreads();
-  unsigned long long t_row = 0, t_a = 0, t_p = 0, t_c = 0, t_da = 0, t_dp = 0, t_dc = 0, t0 = 0, t1 = 0;
-  unsigned long long n_dense_g = 0, n_hash_g = 0, n_dense_e = 0, n_hash_e = 0;
-  const bool timing = (dbg & 32) && threadIdx.x == 0;
-  // Work items come from a device-wide queue (rows cost anything from 5 k to 10 M products, so a static
-  // split leaves a long tail).  An item is (row, part): rows with a very long A row are cut into `parts`
-  // items that take the row's chunk groups round-robin — groups are independent pieces of the output.
-  const uint32_t n_items = n_rows * parts;
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) item_s = atomicAdd(queue, 1u);
-    __syncthreads();
-    const uint32_t item = item_s;
-    if (item >= n_items) break;
-    const uint32_t ri = item / parts, part = item % parts;
+  // the workgroup's item sequence: runs of ITEM_RUN consecutive queue positions; `pos` walks the current run
+  uint32_t run_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_s), run_next = 0xFFFFFFFFu, pos = 0;
+  __syncthreads();
+  auto item_index = [&](uint32_t ahead) -> uint32_t {  // queue position of the item `ahead` steps after the current one
+    const uint32_t q = pos + ahead;
+    if (q < ITEM_RUN) return run_base < n_items ? run_base + q : 0xFFFFFFFFu;
+    return run_next < n_items ? run_next + (q - ITEM_RUN) : 0xFFFFFFFFu;  // (ahead <= 3: the next run is known from pos 1 on)
+  };
+  auto load_item = [&](uint32_t idx, HeavyItem& it) {
+    it.n_a = 0, it.cnt = 0, it.j0 = 0, it.j1_kind = 0, it.a_start = 0, it.out = 0;
+    if (idx < n_items) it = items[idx];  // uniform address: scalar loads
+  };
+  // The first 64 entries of A's row (in a sorted row the lowest columns: R-MAT's hub vertices, whose B rows hold most of
+  // the item's products) are SHARED: every wavefront holds all of them, lane l entry l, and multiplies its 1/NW slice of
+  // each segment — otherwise the wavefront owning the hub runs several times longer than the others.  The entries
+  // after them are OWNED: thread (wave w, lane l) owns entry 64 + l * NW + w when the row has at most 64 + TPB entries
+  // (registers for the whole item); longer rows stream them in 64-entry batches per wavefront.
+  auto fetch_entry = [&](const HeavyItem& it, uint32_t& ks, T& as, uint32_t& ko, T& ao) {
+    ks = 0xFFFFFFFFu, ko = 0xFFFFFFFFu, as = T(0), ao = T(0);
+    if (lane < it.n_a) {
+      ks = a_col[it.a_start + lane];
+      as = a_val[it.a_start + lane];
+    }
+    const uint32_t e = 64 + lane * NW + wave;
+    if (it.n_a <= (uint32_t)(64 + TPB) && e < it.n_a) {
+      ko = a_col[it.a_start + e];
+      ao = a_val[it.a_start + e];
+    }
+  };
+  auto fetch_range = [&](uint32_t j0, uint32_t j1, uint32_t k, uint32_t& lo, uint32_t& len) {
+    lo = 0, len = 0;
+    if (k != 0xFFFFFFFFu) {
+      if (USE_BPOS) {
+        lo = bpos[(uint64_t)j0 * rows_b + k];
+        len = bpos[(uint64_t)j1 * rows_b + k] - lo;
+      } else {
+        lo = (uint32_t)b_rp[k];
+        len = (uint32_t)b_rp[k + 1] - lo;
+      }
+    }
+  };
+  HeavyItem it_c, it_n, it_nn, it_n3;  // descriptors are read two items before their entries are requested
+  uint32_t ks_c, ks_n, ks_nn, los_c, lens_c, los_n, lens_n;  // shared entry: current / next / next-next item
+  uint32_t ko_c, ko_n, ko_nn, loo_c, leno_c, loo_n, leno_n;  // owned entry
+  T as_c, as_n, as_nn, ao_c, ao_n, ao_nn;
+  load_item(item_index(0), it_c);
+  load_item(item_index(1), it_n);
+  load_item(item_index(2), it_nn);
+  fetch_entry(it_c, ks_c, as_c, ko_c, ao_c);
+  fetch_entry(it_n, ks_n, as_n, ko_n, ao_n);
+  fetch_range(it_c.j0, it_c.j1_kind & ~ITEM_DENSE, ks_c, los_c, lens_c);
+  fetch_range(it_c.j0, it_c.j1_kind & ~ITEM_DENSE, ko_c, loo_c, leno_c);
+  // LDS starts dense-clean (all zero); make it hash-clean if the first item is a hash group
+  if (it_c.cnt && !(it_c.j1_kind & ITEM_DENSE)) {
+    for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += TPB) a4[i] = (u32x4)(EMPTY_KEY);
+  }
+  __syncthreads();
+  while (it_c.cnt) {  // cnt == 0 marks the end of the queue
     if (timing) t0 = clock64();
-    const uint32_t row = rows_list[ri];
-    const uint32_t hrow = hrow_of_row[row];
-    const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
-    const uint64_t out_row = c_rp[row];
-    const uint32_t* hc = hcnt + (uint64_t)hrow * nchunks;
-    const uint32_t* ho = hoff + (uint64_t)hrow * nchunks;
-    const bool cached = (pe - ps) <= SEG;
-    if (cached && threadIdx.x < SEG && ps + threadIdx.x < pe) {
-      klist[threadIdx.x] = a_col[ps + threadIdx.x];
-      kval[threadIdx.x] = a_val[ps + threadIdx.x];
-    }
-    // group starts: chunk j opens a group if it or its predecessor is dense, or its offset enters a new window
-    {
-      uint32_t startflag = 0, myoff = 0;
-      const uint32_t j = threadIdx.x;
-      if (j < nchunks) {
-        myoff = ho[j];
-        const bool dj = hc[j] > HWIN;
-        if (j == 0)
-          startflag = 1;
-        else
-          startflag = dj || (hc[j - 1] > HWIN) || (myoff / HWIN != ho[j - 1] / HWIN);
-      }
-      const uint32_t pos = block_excl_scan<TPB>(startflag, wsum);
-      if (startflag) {
-        gbeg[pos] = (uint16_t)j;
-        goff[pos] = myoff;
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const uint32_t ng = wsum[TPB / 64];
-        ng_s = ng;
-        gbeg[ng] = (uint16_t)nchunks;
-        goff[ng] = row_nnz[row];
-      }
-      __syncthreads();
-    }
-    const uint32_t ng = ng_s;
+    // the run after this one is claimed while the first item of a run is processed and read at its end
+    unsigned int claimed = 0;
+    if (pos == 0 && threadIdx.x == 0) claimed = atomicAdd(queue, ITEM_RUN);
+    const uint32_t j0 = it_c.j0, j1 = it_c.j1_kind & ~ITEM_DENSE;
+    const bool dense = (it_c.j1_kind & ITEM_DENSE) != 0;
+    const uint32_t c0 = j0 << CW_SHIFT, cspan = (j1 - j0) << CW_SHIFT;
+    // prefetch: B-split lookups of the next item (its entries were requested an item ago), entries of the one after
+    fetch_range(it_n.j0, it_n.j1_kind & ~ITEM_DENSE, ks_n, los_n, lens_n);
+    fetch_range(it_n.j0, it_n.j1_kind & ~ITEM_DENSE, ko_n, loo_n, leno_n);
+    load_item(item_index(3), it_n3);
+    fetch_entry(it_nn, ks_nn, as_nn, ko_nn, ao_nn);
     if (timing) {
-      t1 = clock64();
-      t_row += t1 - t0;
+      const unsigned long long t1 = clock64();
+      wg_stat[0] += t1 - t0, wg_stat[10] += 1;
+      t0 = t1;
     }
-    uint32_t pf_lo = 0, pf_len = 0, pf_g = 0xFFFFFFFFu;
-    for (uint32_t g = part; g < ng; g += parts) {
-      if (timing) t0 = clock64();
-      const uint32_t j0 = gbeg[g], j1 = gbeg[g + 1];
-      const uint32_t off0 = goff[g], cnt = goff[g + 1] - off0;
-      if (cnt == 0) continue;
-      const bool dense = (j1 == j0 + 1) && cnt > HWIN;
-      const uint32_t c0 = j0 << CW_SHIFT, cspan = (j1 - j0) << CW_SHIFT;
-      if (threadIdx.x == 0) {  // group census for spam_spgemm_stats: kept in registers, one flush per workgroup (3 M groups
-        if (dense) {           // adding to one line of HBM serialise at ~12 ns each: 70 ms of atomic traffic per product)
-          ++n_dense_g;
-          n_dense_e += cnt;
-        } else {
-          ++n_hash_g;
-          n_hash_e += cnt;
+    unsigned long long* wstat = timing ? wg_stat + 1 : nullptr;
+    // ---- products: every wavefront on its own ---------------------------------------------------------------
+    wave_products<T, HTSIZE - 1>(los_c, lens_c, as_c, true, NW, wave, b_col, b_val, c0, cspan, dense, acc, flags, hkeys, hvals, wstat);
+    if (it_c.n_a <= (uint32_t)(64 + TPB)) {
+      if (it_c.n_a > 64)  // (uniform)
+        wave_products<T, HTSIZE - 1>(loo_c, leno_c, ao_c, false, NW, wave, b_col, b_val, c0, cspan, dense, acc, flags, hkeys, hvals, wstat);
+    } else {
+      // streamed A row: after the shared head, wavefront w takes the 64-entry batches w, w + NW, ...; while batch i is
+      // multiplied the B-split lookups of batch i + 1 and the entries of batch i + 2 are in flight
+      const uint64_t ps = it_c.a_start + 64, pe = it_c.a_start + it_c.n_a;
+      const uint64_t nb = ((uint64_t)it_c.n_a - 64 + 63) >> 6;
+      auto s_entry = [&](uint64_t bb, uint32_t& k, T& a) {
+        const uint64_t p = ps + (bb << 6) + lane;
+        k = 0xFFFFFFFFu, a = T(0);
+        if (bb < nb && p < pe) {
+          k = a_col[p];
+          a = a_val[p];
         }
+      };
+      uint32_t k1, k2, lo1, len1;
+      T a1, a2;
+      s_entry(wave, k1, a1);
+      s_entry(wave + NW, k2, a2);
+      fetch_range(j0, j1, k1, lo1, len1);
+      for (uint64_t b = wave; b < nb; b += NW) {
+        const uint32_t lo_b = lo1, len_b = len1;
+        const T a_b = a1;
+        fetch_range(j0, j1, k2, lo1, len1);
+        a1 = a2;
+        s_entry(b + 2 * NW, k2, a2);
+        wave_products<T, HTSIZE - 1>(lo_b, len_b, a_b, false, NW, wave, b_col, b_val, c0, cspan, dense, acc, flags, hkeys, hvals, wstat);
       }
-      // make the LDS region clean for this group's mode
-      if (dense && mode == 1) {
-        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += TPB) a4[i] = (u32x4)(0u);
-        mode = 0;
-        __syncthreads();
-      } else if (!dense && mode == 0) {
-        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += TPB) a4[i] = (u32x4)(EMPTY_KEY);
-        mode = 1;
-        __syncthreads();
-      }
-      for (uint64_t pb = ps; pb < pe; pb += SEG) {
-        const uint64_t p = pb + threadIdx.x;
-        uint32_t lo = 0, len = 0;
-        if (threadIdx.x < SEG && p < pe) {
-          uint32_t k;
-          if (cached) {
-            k = klist[threadIdx.x];
-            seg_av[threadIdx.x] = kval[threadIdx.x];
-          } else {
-            k = a_col[p];
-            seg_av[threadIdx.x] = a_val[p];
-          }
-          if (USE_BPOS) {
-            if (cached && pf_g == g) {  // fetched while the previous group was being accumulated
-              lo = pf_lo;
-              len = pf_len;
-            } else {
-              lo = bpos[(uint64_t)j0 * rows_b + k];
-              len = bpos[(uint64_t)j1 * rows_b + k] - lo;
-            }
-            const uint32_t gn = g + parts;
-            if (cached && gn < ng) {  // this lane's B-split lookups of the next group fly during this one
-              pf_lo = bpos[(uint64_t)gbeg[gn] * rows_b + k];
-              pf_len = bpos[(uint64_t)gbeg[gn + 1] * rows_b + k] - pf_lo;
-            }
-          } else {
-            lo = (uint32_t)b_rp[k];
-            len = (uint32_t)b_rp[k + 1] - lo;
-          }
-        }
-        pf_g = g + parts;
-        uint32_t total;
-        const uint32_t st = block_excl_scan_tot<TPB>(len, wsum, total);
-        if (threadIdx.x < SEG) {
-          seg_start[threadIdx.x] = st;
-          seg_lo[threadIdx.x] = lo - st;  // q = seg_lo[s] + idx for a product index idx of segment s
-        }
-        if (threadIdx.x == 0) seg_start[SEG] = total;
-        __syncthreads();
-        if (timing) {
-          t1 = clock64();
-          (dense ? t_da : t_a) += t1 - t0;
-          t0 = t1;
-          atomicAdd(&gstats[parts > 1 ? 11 : 12], 1ull);          // (group, batch) iterations: giant / normal rows
-          atomicAdd(&gstats[parts > 1 ? 13 : 14], (unsigned long long)total);  // products
-        }
-        // products per lane and round: HEAVY_U when there is enough work, fewer when the group is small so that
-        // all wavefronts share it (the chain of LDS round trips per lane is what a small group waits for)
-        const uint32_t upl = total >= TPB * HEAVY_U ? HEAVY_U : (total + TPB - 1) / TPB;
-        for (uint32_t wb = (threadIdx.x >> 6) * (64 * upl); wb < total; wb += TPB * upl) {
-          const uint32_t idx0 = wb + (threadIdx.x & 63);
-          uint32_t sg = seg_find(seg_start, SEG, idx0 < total ? idx0 : total - 1);
-          uint32_t cols[HEAVY_U];
-          T prods[HEAVY_U];
-#pragma unroll
-          for (int j = 0; j < HEAVY_U; ++j) {
-            const uint32_t idx = idx0 + j * 64;
-            cols[j] = 0xFFFFFFFFu;
-            prods[j] = T(0);
-            if (j < upl && idx < total) {
-              sg = seg_advance(seg_start, SEG, sg, idx);
-              const uint32_t q = seg_lo[sg] + idx;
-              cols[j] = b_col[q];
-              prods[j] = seg_av[sg] * b_val[q];  // t * t1 (mul_hash.rs:154)
-            }
-          }
-          bool okv[HEAVY_U];
-#pragma unroll
-          for (int j = 0; j < HEAVY_U; ++j) okv[j] = cols[j] != 0xFFFFFFFFu && (cols[j] - c0) < cspan;
-          if (dense) {
-#pragma unroll
-            for (int j = 0; j < HEAVY_U; ++j) {
-              if (okv[j]) {
-                const uint32_t c = cols[j] - c0;
-                lds_add(&acc[c], prods[j]);
-                flags[c] = 1;
-              }
-            }
-          } else {
-            lds_map_upsert_batch<T, HEAVY_U, true>(hkeys, hvals, HTSIZE - 1, cols, prods, okv);
-          }
-        }
-        __syncthreads();
-      }
-      uint64_t out = out_row + off0;
+    }
+    if (timing) t0 = clock64();
+    __syncthreads();  // all products of the group are in LDS
+    const uint64_t out = it_c.out;
+    const uint32_t cnt = it_c.cnt;
+    const bool next_dense = it_n.cnt ? (it_n.j1_kind & ITEM_DENSE) != 0 : dense;
+    if (timing) {
+      const unsigned long long t1 = clock64();
+      wg_stat[6] += t1 - t0;
+      t0 = t1;
+    }
+    if (dense) {
+      // column order: wavefront w owns columns [w * DCOLS, (w + 1) * DCOLS), 64 consecutive columns per step
+      const u32x4 fw = f4[wave * (DCOLS / 16) + lane];
+      uint32_t n = __popc(fw.x) + __popc(fw.y) + __popc(fw.z) + __popc(fw.w);
+      n = wave_total_u32(n);
+      if (lane == 0) wsum[wave] = n;
+      __syncthreads();
       if (timing) {
-        t1 = clock64();
-        (dense ? t_dp : t_p) += t1 - t0;
+        const unsigned long long t1 = clock64();
+        wg_stat[7] += t1 - t0;
         t0 = t1;
       }
-      if (dense) {
-        // column order: thread t owns columns [16 t, 16 t + 16)
-        const u32x4 w = f4[threadIdx.x];
-        const uint32_t n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
-        const uint32_t ex = block_excl_scan<TPB>(n, wsum);
-        if (n) {
-          out += ex;
-          f4[threadIdx.x] = (u32x4)(0u);
-          const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+      uint32_t run = 0;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            if ((ww[j >> 2] >> ((j & 3) * 8)) & 1u) {
-              const uint32_t c = threadIdx.x * 16 + j;
-              c_col[out] = c0 + c;
-              c_val[out] = acc[c];
-              acc[c] = T(0);
-              ++out;
-            }
+      for (int i = 0; i < NW; ++i) run += (i < (int)wave) ? wsum[i] : 0u;
+      if (n) {  // (uniform per wavefront)
+        const uint64_t lt = (1ull << lane) - 1ull;
+        const uint8_t* fl = flags + wave * DCOLS + lane;
+#pragma unroll 4
+        for (int s = 0; s < (int)(DCOLS / 64); ++s) {
+          const bool occ = fl[64 * s] != 0;
+          const uint64_t m = __ballot(occ);
+          if (occ) {
+            const uint32_t c = wave * DCOLS + 64 * s + lane;
+            const uint64_t o = out + run + __popcll(m & lt);
+            c_col[o] = c0 + c;
+            c_val[o] = acc[c];
+            acc[c] = T(0);
           }
+          run += (uint32_t)__popcll(m);
         }
-      } else if (SORT) {
-        // B2 = true (mul_hash.rs:164-175): bitonic sort of the whole table by key (u32::MAX = empty sorts
-        // last), after which the group's entries are slots [0, cnt)
-        for (uint32_t k = 2; k <= HTSIZE; k <<= 1) {
-          for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < HTSIZE; i += TPB) {
-              const uint32_t l = i ^ j;
-              if (l > i) {
-                const uint32_t ki = hkeys[i], kl = hkeys[l];
-                if ((ki > kl) == ((i & k) == 0)) {
-                  hkeys[i] = kl;
-                  hkeys[l] = ki;
-                  const T t = hvals[i];
-                  hvals[i] = hvals[l];
-                  hvals[l] = t;
-                }
+        f4[wave * (DCOLS / 16) + lane] = (u32x4)(0u);
+      }
+      if (!next_dense) {
+        // hash-clean for the next item: the key region is the first HTSIZE * 4 bytes of acc = the slices of the first
+        // NW / 4 wavefronts, each of which converts the slice it has just drained
+        if (wave * DCOLS * sizeof(T) < HTSIZE * 4) {
+          u32x4* mine4 = (u32x4*)((char*)acc + wave * DCOLS * sizeof(T));
+          const uint32_t bytes = (uint32_t)(DCOLS * sizeof(T));
+          const uint32_t lim = (uint32_t)(HTSIZE * 4 - wave * DCOLS * sizeof(T));
+          for (uint32_t i = lane; i < (bytes < lim ? bytes : lim) / 16; i += 64) mine4[i] = (u32x4)(EMPTY_KEY);
+        }
+      }
+    } else if (SORT) {
+      // B2 = true (mul_hash.rs:164-175): bitonic sort of the whole table by key (u32::MAX = empty sorts
+      // last), after which the group's entries are slots [0, cnt)
+      for (uint32_t k = 2; k <= HTSIZE; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          for (uint32_t i = threadIdx.x; i < HTSIZE; i += TPB) {
+            const uint32_t l = i ^ j;
+            if (l > i) {
+              const uint32_t ki = hkeys[i], kl = hkeys[l];
+              if ((ki > kl) == ((i & k) == 0)) {
+                hkeys[i] = kl;
+                hkeys[l] = ki;
+                const T t = hvals[i];
+                hvals[i] = hvals[l];
+                hvals[l] = t;
               }
             }
-            __syncthreads();
           }
-        }
-        for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
-          c_col[out + i] = hkeys[i];
-          c_val[out + i] = hvals[i];
-          hkeys[i] = EMPTY_KEY;
-          hvals[i] = T(0);
-        }
-      } else {
-        // slot order (map.rs:59-63): thread t owns slots [8 t, 8 t + 8)
-        constexpr int SPT = HTSIZE / TPB;
-        uint32_t kk[SPT];
-        uint32_t n = 0;
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-          kk[j] = hkeys[threadIdx.x * SPT + j];
-          n += kk[j] != EMPTY_KEY;
-        }
-        const uint32_t ex = block_excl_scan<TPB>(n, wsum);
-        if (n) {
-          out += ex;
-#pragma unroll
-          for (int j = 0; j < SPT; ++j) {
-            if (kk[j] != EMPTY_KEY) {
-              const uint32_t slot = threadIdx.x * SPT + j;
-              c_col[out] = kk[j];
-              c_val[out] = hvals[slot];
-              hkeys[slot] = EMPTY_KEY;
-              hvals[slot] = T(0);
-              ++out;
-            }
-          }
+          __syncthreads();
         }
       }
+      for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
+        c_col[out + i] = hkeys[i];
+        c_val[out + i] = hvals[i];
+        hkeys[i] = EMPTY_KEY;
+        hvals[i] = T(0);
+      }
+      if (next_dense) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += TPB) a4[i] = (u32x4)(0u);
+      }
+    } else {
+      // slot order (map.rs:59-63): wavefront w owns slots [w * HSLOTS, (w + 1) * HSLOTS), 64 consecutive slots per step
+      uint32_t kk[HSLOTS / 64];
+      uint32_t n = 0;
+#pragma unroll
+      for (int s = 0; s < (int)(HSLOTS / 64); ++s) {
+        kk[s] = hkeys[wave * HSLOTS + 64 * s + lane];
+        n += kk[s] != EMPTY_KEY;
+      }
+      n = wave_total_u32(n);
+      if (lane == 0) wsum[wave] = n;
       __syncthreads();
       if (timing) {
-        t1 = clock64();
-        (dense ? t_dc : t_c) += t1 - t0;
+        const unsigned long long t1 = clock64();
+        wg_stat[7] += t1 - t0;
+        t0 = t1;
+      }
+      uint32_t run = 0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) run += (i < (int)wave) ? wsum[i] : 0u;
+      if (n) {
+        const uint64_t lt = (1ull << lane) - 1ull;
+        T vv[HSLOTS / 64];
+#pragma unroll
+        for (int s = 0; s < (int)(HSLOTS / 64); ++s) vv[s] = hvals[wave * HSLOTS + 64 * s + lane];  // all reads in flight
+#pragma unroll
+        for (int s = 0; s < (int)(HSLOTS / 64); ++s) {
+          const bool occ = kk[s] != EMPTY_KEY;
+          const uint64_t m = __ballot(occ);
+          if (occ) {
+            const uint32_t slot = wave * HSLOTS + 64 * s + lane;
+            const uint64_t o = out + run + __popcll(m & lt);
+            c_col[o] = kk[s];
+            c_val[o] = vv[s];
+            hvals[slot] = T(0);
+            if (!next_dense) hkeys[slot] = EMPTY_KEY;
+          }
+          run += (uint32_t)__popcll(m);
+        }
+      }
+      if (next_dense) {  // dense-clean for the next item: this wavefront's key slots become zeros
+        u32x4* mine4 = (u32x4*)(hkeys + wave * HSLOTS);
+        for (uint32_t i = lane; i < HSLOTS * 4 / 16; i += 64) mine4[i] = (u32x4)(0u);
       }
     }
+    if (pos == 0 && threadIdx.x == 0) run_s = claimed;
+    if (timing) {
+      const unsigned long long t1 = clock64();
+      wg_stat[8] += t1 - t0;
+      t0 = t1;
+    }
+    __syncthreads();  // LDS is clean again (in the next item's mode); the claimed run is visible
+    if (pos == 0) run_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_s);
+    if (timing) wg_stat[9] += clock64() - t0;
+    // advance the sequence and shift the prefetch pipeline
+    if (++pos == ITEM_RUN) {
+      pos = 0;
+      run_base = run_next;
+      run_next = 0xFFFFFFFFu;
+    }
+    it_c = it_n, it_n = it_nn, it_nn = it_n3;
+    ks_c = ks_n, as_c = as_n, los_c = los_n, lens_c = lens_n;
+    ko_c = ko_n, ao_c = ao_n, loo_c = loo_n, leno_c = leno_n;
+    ks_n = ks_nn, as_n = as_nn, ko_n = ko_nn, ao_n = ao_nn;
   }
-  if (threadIdx.x == 0) {
-    if (n_dense_g) atomicAdd(&gstats[0], n_dense_g), atomicAdd(&gstats[2], n_dense_e);
-    if (n_hash_g) atomicAdd(&gstats[1], n_hash_g), atomicAdd(&gstats[3], n_hash_e);
-  }
-  if (timing) {
-    atomicAdd(&gstats[4], t_row);
-    atomicAdd(&gstats[5], t_a);
-    atomicAdd(&gstats[6], t_p);
-    atomicAdd(&gstats[7], t_c);
-    atomicAdd(&gstats[8], t_da);
-    atomicAdd(&gstats[9], t_dp);
-    atomicAdd(&gstats[10], t_dc);
-  }
+  if (timing)
+    for (int i = 0; i < 11; ++i) atomicAdd(&gstats[4 + i], wg_stat[i]);
 }
 
 // ---- B2: sort each row by column (mul_hash.rs:164-175) ----------------------------------------------
@@ -1601,6 +1933,43 @@ __global__ __launch_bounds__(1024) void sort_long_rows_kernel(const uint32_t* __
   }
 }
 
+// in place: hist[0 .. n) -> exclusive prefix, hist[n] = total.  One workgroup (n = 2 * chunks: a few hundred to a million).
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(uint32_t* __restrict__ hist, uint32_t n) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) sum += hist[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const uint32_t c = part[i];
+      part[i] = run;
+      run += c;
+    }
+    hist[n] = run;
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t c = hist[i];
+    hist[i] = run;
+    run += c;
+  }
+}
+
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
 }  // namespace spam
 
 // ---- plan ---------------------------------------------------------------------------------------------
@@ -1616,7 +1985,7 @@ struct spam_spgemm_plan {
   const uint32_t* b_col = nullptr;  // B's arrays as the heavy kernels see them
   const void* b_val = nullptr;
   uint32_t n_heavy = 0, nchunks = 0;
-  int cw_shift = spam::CW_SHIFT_LARGE;
+  int cw_shift = spam::CW_SHIFT_512;
   bool use_bpos = false;
   spam_spgemm_stats st{};
   hipEvent_t ev[6] = {};
@@ -1832,16 +2201,14 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
   // heavy rows: dense flags per symbolic chunk
   p->n_heavy = hc[NSYM - 1];
   {
-    const char* cfg = getenv("SPAM_HEAVY_TPB");  // 512 / 1024: force a heavy-path geometry (A/B runs)
-    const uint64_t nch_small = (b->cols + (1u << CW_SHIFT_SMALL) - 1) >> CW_SHIFT_SMALL;
-    const bool small_ok = nch_small <= MAXCH_SMALL;
-    p->cw_shift = (small_ok && cfg && atoi(cfg) == 512) ? CW_SHIFT_SMALL : CW_SHIFT_LARGE;  // 512: 10 % slower
+    const char* cfg = getenv("SPAM_HEAVY_TPB");  // 256 / 512 / 1024: force a heavy-path geometry (A/B runs)
+    const int forced = cfg ? atoi(cfg) : 0;
+    const uint64_t nch512 = (b->cols + (1u << CW_SHIFT_512) - 1) >> CW_SHIFT_512;
+    p->cw_shift = forced == 256 ? CW_SHIFT_256 : forced == 1024 ? CW_SHIFT_1024 : forced == 512 ? CW_SHIFT_512
+                  : (nch512 > WIDE_B_CHUNKS ? CW_SHIFT_1024 : CW_SHIFT_512);
     p->nchunks = (uint32_t)((b->cols + (1ull << p->cw_shift) - 1) >> p->cw_shift);
   }
   if (p->n_heavy) {
-    if (p->nchunks > MAXCH_LARGE)
-      return set_error(SPAM_E_UNSUPPORTED, "rows with more than 4096 intermediate products need cols(B) <= %u",
-                       MAXCH_LARGE << CW_SHIFT_LARGE);
     SPAM_TRY(p->heavy_rows.alloc((uint64_t)p->n_heavy * 4));
     SPAM_HIP_TRY(hipMemcpyAsync(p->heavy_rows.p, L + (uint64_t)(NSYM - 1) * rows, (uint64_t)p->n_heavy * 4,
                                 hipMemcpyDeviceToDevice, s));
@@ -1869,7 +2236,7 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     }
     SPAM_TRY(p->hcnt.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
     SPAM_TRY(p->hoff.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
-    const unsigned grid = std::min<uint32_t>(p->n_heavy, HEAVY_GRID);  // gridDim.x * 1024 must stay below 2^32
+    const unsigned grid = std::min<uint32_t>(p->n_heavy, HEAVY_GRID);
     DevBuf sym_order, otmp;
     SPAM_TRY(sym_order.alloc((uint64_t)p->n_heavy * 4));
     SPAM_TRY(otmp.alloc(64 * 4));
@@ -1949,53 +2316,60 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     const char* dbg_env = getenv("SPAM_DBG_HEAVY");  // 32: print in-kernel phase timers (results unaffected)
     const int dbg_heavy = dbg_env ? atoi(dbg_env) : 0;
     const uint32_t* hl = L + (uint64_t)(NNUM - 1) * rows;
-    DevBuf gst, split;
+    // work items: one per (row, chunk group), bucketed by first chunk (dense before hash) = the queue order
+    const uint32_t nbuckets = 2 * p->nchunks;
+    const uint32_t htsize = (1u << p->cw_shift) / 2, hwin = HEAVY_LOAD_16THS * htsize / 32, hcap = 2 * hwin;
+    DevBuf gst, hist, items;
     SPAM_TRY(gst.alloc(256));
-    SPAM_TRY(split.alloc((uint64_t)n_hnum * 8));
+    SPAM_TRY(hist.alloc(((uint64_t)nbuckets + 2) * 4));
     SPAM_HIP_TRY(hipMemsetAsync(gst.p, 0, 256, s));
-    uint32_t* qcnt = (uint32_t*)(gst.as<unsigned long long>() + 16);  // [0..1] split counts, [2..3] work queues
-    uint32_t* l_normal = split.as<uint32_t>();
-    uint32_t* l_giant = l_normal + n_hnum;
-    split_giant_kernel<<<(n_hnum + 255) / 256, 256, 0, s>>>(hl, n_hnum, a->row_ptr, GIANT_NNZ_A, l_normal, l_giant, qcnt);
+    SPAM_HIP_TRY(hipMemsetAsync(hist.p, 0, ((uint64_t)nbuckets + 2) * 4, s));
+    unsigned long long* census = gst.as<unsigned long long>();           // [0..3] census, [4..10] phase timers
+    uint32_t* queue = (uint32_t*)(gst.as<unsigned long long>() + 16);    // work queue head
+    const unsigned gg = (unsigned)(((uint64_t)n_hnum * 64 + 255) / 256);
+    heavy_groups_kernel<false><<<gg, 256, 0, s>>>(hl, n_hnum, p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hcnt.as<uint32_t>(),
+                                                  p->hoff.as<uint32_t>(), a->row_ptr, crp, hwin, hcap, hist.as<uint32_t>(),
+                                                  nullptr, census);
     SPAM_CHECK_LAUNCH();
-    uint32_t hsplit[2];
-    SPAM_HIP_TRY(hipMemcpyAsync(hsplit, qcnt, 8, hipMemcpyDeviceToHost, s));
+    bucket_scan_kernel<<<1, 1024, 0, s>>>(hist.as<uint32_t>(), nbuckets);
+    SPAM_CHECK_LAUNCH();
+    uint32_t n_items = 0;
+    SPAM_HIP_TRY(hipMemcpyAsync(&n_items, hist.as<uint32_t>() + nbuckets, 4, hipMemcpyDeviceToHost, s));
     SPAM_HIP_TRY(hipStreamSynchronize(s));
-    DevBuf ordered, otmp;
-    SPAM_TRY(ordered.alloc((uint64_t)std::max<uint32_t>(hsplit[0], 1) * 4));
-    SPAM_TRY(otmp.alloc(64 * 4));
-    SPAM_TRY(order_by_cost(l_normal, hsplit[0], p->flops.as<uint64_t>(), otmp.as<uint32_t>(), ordered.as<uint32_t>(), s));
-    l_normal = ordered.as<uint32_t>();
-#define SPAM_NUM_HEAVY_G(BPOS_, SORT_, TPB_, CWS_, LIST_, N_, PARTS_, Q_)                                          \
-  num_heavy_kernel<T, BPOS_, SORT_, TPB_, CWS_><<<std::min<uint32_t>((N_) * (PARTS_), HEAVY_GRID), TPB_, 0, s>>>( \
-      a->row_ptr, a->col_idx, (const T*)a->vals, b->row_ptr, p->b_col, (const T*)p->b_val,                       \
-      BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, LIST_, N_, PARTS_, Q_,                         \
-      p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn, crp, cc, cv, \
-      gst.as<unsigned long long>(), dbg_heavy)
-    if (dbg_heavy & 64) {  // residency of the two heavy geometries on this device
-      int o512 = 0, o1024 = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o512, num_heavy_kernel<T, true, false, 512, CW_SHIFT_SMALL>, 512, 0);
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1024, num_heavy_kernel<T, true, false, 1024, CW_SHIFT_LARGE>, 1024, 0);
-      fprintf(stderr, "[spam dbg] workgroups per CU: 512-thread geometry %d, 1024-thread geometry %d\n", o512, o1024);
-    }
-#define SPAM_NUM_HEAVY(BPOS_, SORT_, LIST_, N_, PARTS_, Q_)                                       \
-  do {                                                                                            \
-    if (p->cw_shift == CW_SHIFT_SMALL)                                                            \
-      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 512, CW_SHIFT_SMALL, LIST_, N_, PARTS_, Q_);                 \
-    else                                                                                          \
-      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 1024, CW_SHIFT_LARGE, LIST_, N_, PARTS_, Q_);                \
+    SPAM_TRY(items.alloc((uint64_t)std::max<uint32_t>(n_items, 1) * sizeof(HeavyItem)));
+    heavy_groups_kernel<true><<<gg, 256, 0, s>>>(hl, n_hnum, p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hcnt.as<uint32_t>(),
+                                                 p->hoff.as<uint32_t>(), a->row_ptr, crp, hwin, hcap, hist.as<uint32_t>(),
+                                                 items.as<HeavyItem>(), census);
+    SPAM_CHECK_LAUNCH();
+#define SPAM_NUM_HEAVY_G(BPOS_, SORT_, TPB_, CWS_)                                                                   \
+  do {                                                                                                               \
+    auto kern = num_heavy_kernel<T, BPOS_, SORT_, TPB_, CWS_>;                                                       \
+    int per_cu = 0;                                                                                                  \
+    SPAM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, TPB_, 0));                              \
+    if (per_cu < 1) per_cu = 1;                                                                                      \
+    const uint64_t resident = (uint64_t)per_cu * (uint64_t)device_cus();                                             \
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(resident, (n_items + ITEM_RUN - 1) / ITEM_RUN)); \
+    if (dbg_heavy & 64) fprintf(stderr, "[spam dbg] heavy numeric: %d threads, %d workgroups per CU, grid %u, %u items\n", TPB_, per_cu, grid, n_items); \
+    kern<<<grid, TPB_, 0, s>>>(a->col_idx, (const T*)a->vals, b->row_ptr, p->b_col, (const T*)p->b_val,              \
+                               BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, items.as<HeavyItem>(),   \
+                               n_items, queue, cc, cv, census, dbg_heavy);                                           \
   } while (0)
-#define SPAM_NUM_HEAVY_BOTH(BPOS_, SORT_)                                                              \
-  do {                                                                                                 \
-    if (hsplit[1]) SPAM_NUM_HEAVY(BPOS_, SORT_, l_giant, hsplit[1], GIANT_PARTS, qcnt + 2); /* first */ \
-    if (hsplit[0]) SPAM_NUM_HEAVY(BPOS_, SORT_, l_normal, hsplit[0], 1u, qcnt + 3);                     \
+#define SPAM_NUM_HEAVY(BPOS_, SORT_)                                                        \
+  do {                                                                                      \
+    if (p->cw_shift == CW_SHIFT_256)                                                        \
+      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 256, CW_SHIFT_256);                                    \
+    else if (p->cw_shift == CW_SHIFT_512)                                                   \
+      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 512, CW_SHIFT_512);                                    \
+    else                                                                                    \
+      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 1024, CW_SHIFT_1024);                                  \
   } while (0)
-    if (p->use_bpos) {
-      if (sort_rows == 1) SPAM_NUM_HEAVY_BOTH(true, true); else SPAM_NUM_HEAVY_BOTH(true, false);
-    } else {
-      if (sort_rows == 1) SPAM_NUM_HEAVY_BOTH(false, true); else SPAM_NUM_HEAVY_BOTH(false, false);
+    if (n_items) {
+      if (p->use_bpos) {
+        if (sort_rows == 1) SPAM_NUM_HEAVY(true, true); else SPAM_NUM_HEAVY(true, false);
+      } else {
+        if (sort_rows == 1) SPAM_NUM_HEAVY(false, true); else SPAM_NUM_HEAVY(false, false);
+      }
     }
-#undef SPAM_NUM_HEAVY_BOTH
 #undef SPAM_NUM_HEAVY
 #undef SPAM_NUM_HEAVY_G
     SPAM_CHECK_LAUNCH();
@@ -2003,12 +2377,13 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     unsigned long long hg[16];
     SPAM_HIP_TRY(hipMemcpyAsync(hg, gst.p, 128, hipMemcpyDeviceToHost, s));
     SPAM_HIP_TRY(hipStreamSynchronize(s));
-    if (dbg_heavy & 32)
-      fprintf(stderr, "[spam dbg] heavy phase cycles (sum over workgroups): row-setup %llu  groupA %llu  products %llu  compaction %llu  (dense: A %llu prod %llu comp %llu)\n",
-              hg[4], hg[5], hg[6], hg[7], hg[8], hg[9], hg[10]);
-    if (dbg_heavy & 32)
-      fprintf(stderr, "[spam dbg] (group, batch) iterations: giant rows %llu with %llu products, other rows %llu with %llu products; giant rows %u, other %u\n",
-              hg[11], hg[13], hg[12], hg[14], hsplit[1], hsplit[0]);
+    if (dbg_heavy & 32) {
+      const double ni = (double)(hg[14] ? hg[14] : 1);
+      fprintf(stderr, "[spam dbg] heavy numeric, cycles per item (thread 0 of every workgroup): prefetch issue %.0f | wave 0: long pieces %.0f, "
+              "short segments: search + load issue %.0f, load wait %.0f, upserts %.0f (%.2f rounds) | products barrier %.0f | drain count + "
+              "barrier %.0f | drain %.0f | closing barrier %.0f; %u rows, %u items\n", hg[4] / ni, hg[9] / ni, hg[5] / ni, hg[6] / ni,
+              hg[7] / ni, hg[8] / ni, hg[10] / ni, hg[11] / ni, hg[12] / ni, hg[13] / ni, n_hnum, n_items);
+    }
     st.heavy_dense_groups = hg[0], st.heavy_hash_groups = hg[1], st.heavy_dense_nnz = hg[2], st.heavy_hash_nnz = hg[3];
   }
   if (sort_rows == 2 && n_hnum) {

@@ -184,32 +184,93 @@ def test_row_block_product_equals_slice(spam, oracle):
         assert_csr_parity((o, i, v), (wo, want[1][s:e], want[2][s:e]), True, F64_RTOL)
 
 
-def test_full_size_row_sum_property(spam):
-    """BASELINE configs[2] at full size (R-MAT scale 20: F = 2.09e10 products, nnz(C) = 9.7e9 > 2^32) with a check
-    that needs no CPU product: (A*A)*1 == A*(A*1) row by row, sorted and unsorted output, plus invariants 1-7 of
-    the sorted result on the device."""
+def test_full_size_row_sum_property(spam, oracle):
+    """BASELINE configs[2] at full size (R-MAT scale 20: F = 2.09e10 products, nnz(C) = 9.7e9 > 2^32).
+    (1) a check that needs no CPU product: (A*A)*x == A*(A*x) row by row for a RANDOM positive x (a permuted or
+    corrupted col_idx inside a row changes the row's dot product, unlike x = 1), sorted and unsorted output, plus
+    invariants 1-7 of the sorted result on the device;
+    (2) two bounded row samples of the unsorted product against the oracle — 306 heavy rows from the middle of the
+    matrix and a run of lighter rows near its end: row_ptr exact, column sets equal, values 1e-10, and the same rows
+    in the reference's slot order bit-exact (sort_rows = 2)."""
     import torch
     from sparse_matrix_amd import DeviceCsr
+    from helpers import spgemm_rows_vs_oracle
 
     dev = torch.device("cuda", 0)
     A = synth.rmat(20, dtype=torch.float64, device=dev)
     dA = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, A.vals, True)
-    ones = torch.ones(A.cols, dtype=torch.float64, device=dev)
+    x = synth.dense_vector(A.cols, dtype=torch.float64, device=dev)
     t1, t2, t3 = (torch.empty(A.rows, dtype=torch.float64, device=dev) for _ in range(3))
-    dA.spmv_dev(ones.data_ptr(), t1.data_ptr())
+    dA.spmv_dev(x.data_ptr(), t1.data_ptr())
     dA.spmv_dev(t1.data_ptr(), t2.data_ptr())
+    a_host = A.cpu_numpy()
     for sort_rows in (False, True):
         C, st = dA.spgemm(dA, sort_rows=sort_rows)
         assert st["nnz_c"] > 9_000_000_000 and st["flops_f"] > 20_000_000_000
-        C.spmv_dev(ones.data_ptr(), t3.data_ptr())
+        C.spmv_dev(x.data_ptr(), t3.data_ptr())
         torch.cuda.synchronize()
         rel = ((t3 - t2).abs() / t2.abs().clamp_min(1e-300)).max().item()
         assert rel <= F64_RTOL, rel
         if sort_rows:
             assert C.invariants()
+        else:
+            n = A.rows
+            r1, Fs, nz = spgemm_rows_vs_oracle(oracle, dA, dA, C, a_host, a_host, n // 2, 2e8)
+            assert nz > 10_000_000 and r1 - n // 2 > 100
+            spgemm_rows_vs_oracle(oracle, dA, dA, C, a_host, a_host, n - n // 16, 5e7)
         rp = C.download_row_ptr().astype(np.int64)
         assert rp[0] == 0 and rp[-1] == st["nnz_c"] and np.all(np.diff(rp) >= 0)
         C.free()
+
+
+def test_scale22_rank_blocks_cfg4(spam, oracle):
+    """BASELINE configs[3] (8 x MI355X, R-MAT scale 22: F = 1.46e11, nnz(C) = 7.2e10 = 864 GB, which only fits
+    sharded) as far as one GPU can take it: the matrix is built at full size, cut into the 8 row blocks the 8-rank run
+    uses (rows_to_threads on F + 2300 per non-empty row, mul_hash.rs:52-62), and two of the per-rank products
+    C_r = A[block r] * B are run at full size on this GPU — the heaviest block (<= 137 GB of C) and a middle one.
+    Each is checked like the scale-20 product: row sums against A_r*(B*x) for a random x over ALL rows of the block,
+    and bounded row samples against the oracle (row_ptr exact, column sets, 1e-10, reference slot order bit-exact)."""
+    import torch
+    from sparse_matrix_amd import DeviceCsr, _lib
+    from helpers import spgemm_rows_vs_oracle
+
+    dev = torch.device("cuda", 0)
+    A = synth.rmat(22, dtype=torch.float64, device=dev)
+    n = A.rows
+    dB = DeviceCsr.from_torch(n, n, A.row_ptr, A.col_idx, A.vals, True)
+    offs = dB.balanced_row_blocks(dB, 8, 2300)
+    assert offs[0] == 0 and offs[-1] == n and all(b > a for a, b in zip(offs[:-1], offs[1:]))
+    b_host = A.cpu_numpy()
+    x = synth.dense_vector(n, dtype=torch.float64, device=dev)
+    bx = torch.empty(n, dtype=torch.float64, device=dev)
+    dB.spmv_dev(x.data_ptr(), bx.data_ptr())
+    flops, _ = dB.rows_to_parts(dB, 1)
+    cost = [int(flops[offs[r]:offs[r + 1]].sum()) for r in range(8)]
+    heaviest = int(np.argmax([int(b_host[0][offs[r + 1]] - b_host[0][offs[r]]) for r in range(8)]))  # most entries of A
+    total_nnz_c = 0
+    for r in sorted({heaviest, 4}):
+        lo, hi = offs[r], offs[r + 1]
+        dAr = dB.row_block(lo, hi)
+        C, st = dAr.spgemm(dB, sort_rows=False)
+        assert st["flops_f"] == cost[r]
+        total_nnz_c += st["nnz_c"]
+        want = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+        got = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+        dAr.spmv_dev(bx.data_ptr(), want.data_ptr())
+        C.spmv_dev(x.data_ptr(), got.data_ptr())
+        torch.cuda.synchronize()
+        rel = ((got - want).abs() / want.abs().clamp_min(1e-300)).max().item()
+        assert rel <= F64_RTOL, (r, rel)
+        s, e = int(b_host[0][lo]), int(b_host[0][hi])
+        a_host = (b_host[0][lo:hi + 1] - b_host[0][lo], b_host[1][s:e], b_host[2][s:e])
+        for row_lo, target in (((hi - lo) // 2, 1e8), (0, 5e7), ((hi - lo) - max(1, (hi - lo) // 50), 3e7)):
+            spgemm_rows_vs_oracle(oracle, dAr, dB, C, a_host, b_host, row_lo, target)
+        rp = C.download_row_ptr().astype(np.int64)
+        assert rp[-1] == st["nnz_c"] and np.all(np.diff(rp) >= 0)
+        C.free()
+        del C, dAr, want, got
+        _lib.check(_lib.load().spam_hip_trim())
+    assert total_nnz_c > 10_000_000_000
 
 
 def test_matrix_market_bench_shape(spam, oracle, tmp_path):
