@@ -40,6 +40,9 @@ namespace spam {
 constexpr int CW_SHIFT_256 = 12, CW_SHIFT_512 = 13, CW_SHIFT_1024 = 14;
 constexpr uint64_t WIDE_B_CHUNKS = 8192;        // more 2^13-column chunks than this: use the 2^14 geometry
 
+// LDS accumulator of the heavy numeric path: 144 bytes per thread (two 512-thread workgroups per CU)
+__host__ __device__ constexpr uint32_t heavy_region_bytes(int tpb) { return (uint32_t)tpb * 144u; }
+
 constexpr uint32_t HEAVY_GRID = 8192;           // persistent workgroups of the symbolic heavy kernels (1 fits per CU)
 
 constexpr int NSYM = 4;                         // symbolic bins by F
@@ -785,15 +788,29 @@ __global__ __launch_bounds__(256) void cost_scatter_kernel(const uint32_t* __res
   if (i < n) out[base[b] + rank] = r;
 }
 
-// ---- wave-autonomous product streaming (heavy numeric path) --------------------------------------------------
-// One wavefront owns up to 64 entries k of A's row — one per lane, kept in registers: the position range
-// [lo, lo + len) of B's row k that falls into the current chunk group and the value a.  The lengths are prefix-summed
-// across the wave with DPP moves (no LDS) and the wave walks the concatenated product index space 64 * U products per
-// round, lane-contiguous inside every load instruction whatever the mix of short and long segments.  The segment of a
-// product index is found by a search over the lanes' start offsets: two ballots bound the segments a 64-product window
-// touches (a scalar range), the bisection inside that range costs ceil(log2(range + 1)) ds_bpermute rounds — zero when
-// the window lies in one segment.  Nothing here synchronises with other wavefronts, so the 16 wavefronts of a
-// workgroup run out of phase and their global-load latencies overlap; the workgroup meets only at group boundaries.
+// ---- heavy numeric path: wave-autonomous product streaming into a rank-addressed accumulator ------------------
+// A heavy row (more than 4096 entries of C) is cut into GROUPS of consecutive column chunks; every (row, group) is a
+// work item of its own.  A group's entries are accumulated in LDS in two passes over its products:
+//   pass 1  marks the columns that occur:  ds_or on a bitmap over the group's column span (fire and forget);
+//   then every bitmap word gets the number of set bits before it (its entries' first output position);
+//   pass 2  adds each product to vals[rank(col)], rank = word prefix + popcount of the lower bits: one ds_read_b64 and one
+//           ds_add_f64, no compare-and-swap, no probing — the linprobe table this replaces spent most of its time in
+//           data-dependent CAS loops (its longest probe sequence among 64 lanes sets the pace of the wavefront);
+//   drain   vals[0 .. cnt) is already the row piece in COLUMN order: one coalesced copy, the column indices are expanded
+//           from the bitmap.  Heavy rows therefore come out sorted whatever sort_rows says.
+// LDS holds the bitmap words {prefix, bits} followed by the values: 8 * span / 32 + sizeof(T) * cnt bytes must fit
+// REGION, which bounds a group either by its entries (dense stretches: ~8000 entries) or by its span (sparse tails);
+// heavy_groups_kernel packs chunks greedily.  Items are queued in COLUMN-WINDOW order (all groups starting in chunk 0,
+// then chunk 1, ...), so at any moment the workgroups of the whole chip read the same narrow slice of B's rows, which
+// stays in every XCD's L2, instead of all of B.  Workgroups take items in runs of ITEM_RUN consecutive queue
+// positions (one atomic per run) and prefetch across items: while item i is multiplied, the B-split lookups of item
+// i + 1 and the A entries of item i + 2 are in flight.
+// Inside an item the wavefronts stream products on their own (no workgroup barrier inside a pass): the first 64
+// entries of A's row (in a sorted row the lowest columns: R-MAT's hubs, whose B rows hold most of the products) are
+// SHARED — every wavefront holds all of them and takes its share of each segment; the entries after them are OWNED,
+// thread (wave w, lane l) owns entry 64 + l * NW + w; rows longer than 64 + TPB entries stream the rest in 64-entry
+// batches per wavefront.  Segments of 64 or more products are cut into 64-product PIECES with scalar parameters (one
+// coalesced load per piece, no search); shorter ones are walked through a flattened product index space.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
@@ -819,97 +836,67 @@ __device__ __forceinline__ double shfl_val(double v, uint32_t src_lane) {
 __device__ __forceinline__ float shfl_val(float v, uint32_t src_lane) {
   return __builtin_bit_cast(float, shfl_u32(__builtin_bit_cast(uint32_t, v), src_lane));
 }
+__device__ __forceinline__ double readlane_val(double v, uint32_t src_lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, (int)src_lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), (int)src_lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+__device__ __forceinline__ float readlane_val(float v, uint32_t src_lane) {
+  return __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, v), (int)src_lane));
+}
 
 #ifndef SPAM_WAVE_U
 #define SPAM_WAVE_U 4
 #endif
-#ifndef SPAM_HEAVY_PROBE
-#define SPAM_HEAVY_PROBE 0  // 0: linear probing, one key after the other; 1: double hashing, all keys of a round in lockstep
-#endif
 constexpr int WAVE_U = SPAM_WAVE_U;  // products per lane and round: that many independent (col, val) loads in flight per lane
+constexpr uint32_t LONG_SEG = 64;    // segments of at least this many products are cut into scalar pieces
+#ifndef SPAM_PIECE_U
+#define SPAM_PIECE_U 8
+#endif
+constexpr int PIECE_U = SPAM_PIECE_U;  // pieces per round of the long-segment path (two rounds of loads in flight)
 
-// sum over the 64 lanes through DPP moves (no LDS traffic); the total is returned in every lane
-__device__ __forceinline__ uint32_t wave_total_u32(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
-}
+struct RankWord {  // one bitmap word of the group's column span
+  uint32_t prefix;  // entries of the group in lower words (valid after the prefix step)
+  uint32_t bits;
+};
 
-// U upserts per lane into the group's table, all lanes and all U keys probing in lockstep: every pass issues the
-// pending CAS of all U keys back to back (one LDS round trip per pass whatever U is), then the adds of the keys that
-// found their slot.  Double hashing (odd step from a second multiplicative hash): the longest probe sequence among
-// the 64 x U keys of a pass sets the number of passes, and linear probing's clusters make that tail several times
-// longer at load 0.5 - 0.75.  The slot order this produces is this library's own "table order" (sort_rows = 0).
-template <class T, int U>
-__device__ __forceinline__ void lds_map_upsert_rounds(uint32_t* keys, T* vals, uint32_t mask, const uint32_t (&k)[U],
-                                                      const T (&v)[U], const bool (&ok)[U]) {
-  uint32_t h[U], step[U], old[U];
-  bool pend[U];
-  const int sh = __clz(mask);
-#pragma unroll
-  for (int j = 0; j < U; ++j) {
-    h[j] = ((k[j] * 0x9E3779B1u) >> sh) & mask;
-    step[j] = ((k[j] * 0x85EBCA6Bu) >> 23) | 1u;
-    pend[j] = ok[j];
-    old[j] = 0;
-  }
-  for (;;) {
-#pragma unroll
-    for (int j = 0; j < U; ++j)
-      if (pend[j]) old[j] = atomicCAS(&keys[h[j]], EMPTY_KEY, k[j]);
-    bool any = false;
+// One round of WAVE_U products per lane.  PASS 1: mark the columns; PASS 2: add the products at their rank.
+template <class T, int PASS, int U>
+__device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[U], const T (&prods)[U], uint32_t c0,
+                                                 uint32_t cspan, RankWord* words, T* vals) {
+  if (PASS == 1) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      if (pend[j]) {
-        if (old[j] == EMPTY_KEY || old[j] == k[j]) {
-          lds_add(&vals[h[j]], v[j]);
-          pend[j] = false;
-        } else {
-          h[j] = (h[j] + step[j]) & mask;
-          any = true;
-        }
-      }
-    }
-    if (!__any(any)) break;
-  }
-}
-
-// One round of WAVE_U accumulations per lane.  acc / flags: dense accumulator over the group's column window;
-// hkeys / hvals: the group's hash table.
-template <class T, uint32_t HMASK>
-__device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[WAVE_U], const T (&prods)[WAVE_U], uint32_t c0,
-                                                 uint32_t cspan, bool dense, T* acc, uint8_t* flags, uint32_t* hkeys,
-                                                 T* hvals) {
-  bool okv[WAVE_U];
-#pragma unroll
-  for (int j = 0; j < WAVE_U; ++j) okv[j] = cols[j] != EMPTY_KEY && (cols[j] - c0) < cspan;
-  if (dense) {  // (uniform)
-#pragma unroll
-    for (int j = 0; j < WAVE_U; ++j) {
-      if (okv[j]) {
-        const uint32_t c = cols[j] - c0;
-        lds_add(&acc[c], prods[j]);
-        flags[c] = 1;
-      }
+      const uint32_t rel = cols[j] - c0;
+      if (cols[j] != EMPTY_KEY && rel < cspan) atomicOr(&words[rel >> 5].bits, 1u << (rel & 31));
     }
   } else {
-#if SPAM_HEAVY_PROBE
-    lds_map_upsert_rounds<T, WAVE_U>(hkeys, hvals, HMASK, cols, prods, okv);
-#else
-    lds_map_upsert_batch<T, WAVE_U, true>(hkeys, hvals, HMASK, cols, prods, okv);
-#endif
+    RankWord w[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t rel = cols[j] - c0;
+      w[j].prefix = 0, w[j].bits = 0;
+      if (cols[j] != EMPTY_KEY && rel < cspan) w[j] = words[rel >> 5];  // all reads in flight together
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t rel = cols[j] - c0;
+      if (cols[j] != EMPTY_KEY && rel < cspan)
+        lds_add(&vals[w[j].prefix + __popc(w[j].bits & ((1u << (rel & 31)) - 1u))], prods[j]);
+    }
   }
 }
 
-// Long segments (>= LONG_SEG products) are cut into 64-product PIECES whose parameters are scalars (v_readlane of
-// the owning lane's registers): a piece is one coalesced load of columns and one of values at SGPR base + lane,
-// no segment search, no shuffles.  `deal` = NW for the shared entries every wavefront holds (piece p of segment s goes
-// to wavefront (s + p) mod NW, so a hub's products spread evenly over the workgroup) and 1 for entries this
-// wavefront owns alone.  WAVE_U pieces are gathered per round so that their loads are in flight together.
-constexpr uint32_t LONG_SEG = 64;
-
-template <class T, uint32_t HMASK>
+// Long segments: 64-product pieces whose parameters are scalars (v_readlane of the owning lane's registers): a piece
+// is one coalesced load of columns (and one of values in pass 2) at a scalar base + lane, no segment search, no
+// shuffles.  `deal` = NW for the shared entries every wavefront holds (piece p of segment s goes to wavefront
+// (s + p) mod NW, so a hub's products spread evenly over the workgroup) and 1 for entries this wavefront owns alone.
+// WAVE_U pieces are gathered per round so that their loads are in flight together.
+template <class T, int PASS>
 __device__ __forceinline__ void long_pieces(uint64_t lmask, uint32_t lo, uint32_t len, T av, uint32_t deal, uint32_t wave,
                                             const uint32_t* __restrict__ b_col, const T* __restrict__ b_val, uint32_t c0,
-                                            uint32_t cspan, bool dense, T* acc, uint8_t* flags, uint32_t* hkeys, T* hvals) {
+                                            uint32_t cspan, RankWord* words, T* vals) {
   const uint32_t lane = threadIdx.x & 63;
   // scalar piece iterator
   uint64_t m = lmask;
@@ -923,74 +910,62 @@ __device__ __forceinline__ void long_pieces(uint64_t lmask, uint32_t lo, uint32_
       m &= m - 1;
       s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)sidx);
       s_len = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)sidx);
-      if constexpr (sizeof(T) == 8) {
-        const long long b = __builtin_bit_cast(long long, av);
-        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, (int)sidx);
-        const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), (int)sidx);
-        s_a = __builtin_bit_cast(T, ((long long)h0 << 32) | (long long)l0);
-      } else {
-        s_a = __builtin_bit_cast(T, (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, av), (int)sidx));
-      }
+      if (PASS == 2) s_a = readlane_val(av, sidx);
       np = (s_len + 63) >> 6;
       p = deal > 1 ? (wave + deal - (sidx % deal)) % deal : 0u;
     }
   };
   bool more = next_piece();
   while (more) {
-    uint32_t cols[WAVE_U];
-    T prods[WAVE_U], bv[WAVE_U], aa[WAVE_U];
+    uint32_t cols[PIECE_U];
+    T prods[PIECE_U], sa[PIECE_U];  // (sa: one scalar per piece)
 #pragma unroll
-    for (int j = 0; j < WAVE_U; ++j) {
+    for (int j = 0; j < PIECE_U; ++j) {
       cols[j] = EMPTY_KEY;
-      bv[j] = T(0), aa[j] = T(0);
+      prods[j] = T(0), sa[j] = T(0);
       if (more) {  // (uniform)
-        const uint32_t idx = p * 64 + lane;
-        if (idx < s_len) {
-          cols[j] = b_col[(uint64_t)s_lo + idx];
-          bv[j] = b_val[(uint64_t)s_lo + idx];
+        const uint32_t n = s_len - p * 64;  // products left in the segment from this piece on
+        if (lane < n) {
+          const uint64_t q = (uint64_t)s_lo + p * 64 + lane;
+          cols[j] = b_col[q];
+          if (PASS == 2) prods[j] = b_val[q];
         }
-        aa[j] = s_a;
+        sa[j] = s_a;
         p += deal;
         more = next_piece();
       }
     }
+    if (PASS == 2) {  // only now: a multiply right behind its load would make every piece wait for its own round trip
 #pragma unroll
-    for (int j = 0; j < WAVE_U; ++j) prods[j] = aa[j] * bv[j];  // t * t1 (mul_hash.rs:154)
-    accumulate_round<T, HMASK>(cols, prods, c0, cspan, dense, acc, flags, hkeys, hvals);
+      for (int j = 0; j < PIECE_U; ++j) prods[j] = sa[j] * prods[j];  // t * t1 (mul_hash.rs:154)
+    }
+    accumulate_round<T, PASS, PIECE_U>(cols, prods, c0, cspan, words, vals);
   }
 }
 
 // The products of one wavefront's 64 segments (one per lane: positions [lo, lo + len) of B's arrays, value av).
 // shared = true: every wavefront of the workgroup holds the same 64 segments (the head of A's row): long ones are
-// dealt piecewise, a short one goes whole to wavefront lane mod NW.  shared = false: the segments are this wavefront's own.
-// Short segments are walked through the flattened product index space: the lengths are prefix-summed across the wave
-// with DPP moves and the wave takes 64 * WAVE_U consecutive products per round, lane-contiguous inside every load.
-template <class T, uint32_t HMASK>
+// dealt piecewise, a short one goes whole to wavefront lane mod NW.  shared = false: the segments are this wavefront's
+// own.  Short segments are walked through the flattened product index space: the lengths are prefix-summed across the
+// wave with DPP moves and the wave takes 64 * WAVE_U consecutive products per round, lane-contiguous inside every load.
+// The segment of a product index is found by a search over the lanes' start offsets: two ballots bound the segments a
+// 64-product window touches (a scalar range), the bisection inside that range runs for all windows of the round at
+// once, one ds_bpermute round trip per halving — none when a window lies in one segment.
+template <class T, int PASS>
 __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, bool shared, uint32_t nw, uint32_t wave,
-                                              const uint32_t* __restrict__ b_col,
-                                              const T* __restrict__ b_val, uint32_t c0, uint32_t cspan, bool dense,
-                                              T* acc, uint8_t* flags, uint32_t* hkeys, T* hvals,
-                                              unsigned long long* stat = nullptr /* SPAM_DBG_HEAVY=32: thread 0's timers */) {
+                                              const uint32_t* __restrict__ b_col, const T* __restrict__ b_val, uint32_t c0,
+                                              uint32_t cspan, RankWord* words, T* vals) {
   const uint32_t lane = threadIdx.x & 63;
-  unsigned long long q0 = 0, q1 = 0, q2 = 0;
-  if (stat) q0 = clock64();
   const uint64_t lmask = __ballot(len >= LONG_SEG);
-  if (lmask) long_pieces<T, HMASK>(lmask, lo, len, av, shared ? nw : 1u, wave, b_col, b_val, c0, cspan, dense, acc, flags, hkeys, hvals);
+  if (lmask) long_pieces<T, PASS>(lmask, lo, len, av, shared ? nw : 1u, wave, b_col, b_val, c0, cspan, words, vals);
   if (len >= LONG_SEG || (shared && (lane % nw) != wave)) len = 0;
-  if (stat) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    stat[4] += clock64() - q0;
-  }
   const uint32_t inc = wave_incl_scan_u32(len);
   const uint32_t st = inc - len;                         // first product index of this lane's segment
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
   const uint32_t off = lo - st;                          // q = off[s] + idx for a product index idx of segment s
   for (uint32_t base = 0; base < total; base += 64 * WAVE_U) {
-    if (stat) q0 = clock64();
-    // segment search for the WAVE_U windows of this round in lockstep.  st is non-decreasing over the lanes: the lanes
-    // with st <= w form a prefix whose last member is the segment holding product w (empty segments share their
-    // successor's start and are skipped by taking the last), so two ballots bound the segments a 64-product window
-    // touches; the bisection inside [slo, shi] runs for all windows at once, one ds_bpermute round trip per halving.
+    // st is non-decreasing over the lanes: the lanes with st <= w form a prefix whose last member is the segment
+    // holding product w (empty segments share their successor's start and are skipped by taking the last)
     uint32_t slo[WAVE_U], shi[WAVE_U];
     uint32_t maxspan = 0;
 #pragma unroll
@@ -1005,9 +980,6 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
         maxspan = a1 - a0 > maxspan ? a1 - a0 : maxspan;
       }
     }
-#ifdef SPAM_ABLATE_SEARCH
-    maxspan = 0;
-#endif
     for (uint32_t span = maxspan; span != 0; span >>= 1) {  // uniform trip count
       uint32_t v[WAVE_U], mid[WAVE_U];
 #pragma unroll
@@ -1025,7 +997,7 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
       }
     }
     uint32_t cols[WAVE_U], qq[WAVE_U];
-    T bv[WAVE_U];
+    T bv[WAVE_U], aa[WAVE_U], prods[WAVE_U];
 #pragma unroll
     for (int j = 0; j < WAVE_U; ++j) qq[j] = shfl_u32(off, slo[j]);
 #pragma unroll
@@ -1034,83 +1006,41 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
       cols[j] = EMPTY_KEY;
       bv[j] = T(0);
       if (idx < total) {
-#ifdef SPAM_ABLATE_LOADS
-        cols[j] = c0 + ((qq[j] + idx) * 2654435761u) % cspan;
-        bv[j] = T(1);
-#else
         cols[j] = b_col[qq[j] + idx];
-        bv[j] = b_val[qq[j] + idx];
-#endif
+        if (PASS == 2) bv[j] = b_val[qq[j] + idx];
       }
     }
-    T aa[WAVE_U];
 #pragma unroll
-    for (int j = 0; j < WAVE_U; ++j) aa[j] = shfl_val(av, slo[j]);
-    if (stat) {
-      q1 = clock64();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      q2 = clock64();
-    }
-    T prods[WAVE_U];
+    for (int j = 0; j < WAVE_U; ++j) aa[j] = PASS == 2 ? shfl_val(av, slo[j]) : T(0);
 #pragma unroll
     for (int j = 0; j < WAVE_U; ++j) prods[j] = aa[j] * bv[j];  // t * t1 (mul_hash.rs:154)
-    accumulate_round<T, HMASK>(cols, prods, c0, cspan, dense, acc, flags, hkeys, hvals);
-    if (stat) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const unsigned long long q3 = clock64();
-      stat[0] += q1 - q0, stat[1] += q2 - q1, stat[2] += q3 - q2, stat[3] += 1;
-    }
+    accumulate_round<T, PASS, WAVE_U>(cols, prods, c0, cspan, words, vals);
   }
 }
 
-// Numeric pass for heavy rows.  A row's numeric chunks are grouped (heavy_groups_kernel):
-//   * a chunk holding more than HWIN entries (>19 % dense) is accumulated DENSELY: T acc[CW] + byte flags,
-//     LDS float atomics, compaction in column order;
-//   * runs of sparser chunks are merged while their entries stay below HCAP and share one linprobe table
-//     of HTSIZE slots laid over the same LDS (keys u32 + values T), compaction in slot order.
-// Either way a group writes a contiguous, precomputed piece of C's row (hoff), groups are in increasing
-// column order, and every touched LDS slot is reset while it is read out.
-//   HTSIZE = CW/2 slots;  HCAP = load * HTSIZE: a hash group holds fewer entries;  HWIN = HCAP/2: grouping
-//   window / dense threshold.
-// Every (row, group) is a work item of its own, and the items are queued in COLUMN-WINDOW order (all groups starting
-// in chunk 0, then chunk 1, ...; dense before hash inside a chunk).  At any moment the workgroups of the whole chip
-// therefore read the same 1/nchunks slice of B — a few MB that stay in every XCD's L2 — instead of all of B (200 MB
-// at scale 20: 63 % of the L2 lookups missed when every workgroup walked its own row's groups).  Giant A rows need no
-// special casing: their groups are independent items like everyone else's.
-// Workgroups take items in runs of ITEM_RUN consecutive queue positions (one atomic per run) and prefetch across
-// items: while item i is multiplied, the B-split lookups of item i + 1 and the A entries of item i + 2 are in flight.
-// Inside an item the wavefronts stream products on their own (wave_products); the workgroup synchronises three times:
-// products done -> per-wave entry counts -> LDS drained and clean.  A rows of at most TPB entries sit in registers —
-// thread (wave w, lane l) owns entry l * NW + w, so every wavefront gets an even sample of the (sorted) row; longer A
-// rows are streamed in 64-entry batches per wavefront with the same two-stage prefetch.
-// The drain is per wavefront over a contiguous slice of the accumulator: 64 consecutive slots per step, ranked by
-// ballot, so LDS reads are conflict-free and the stores to C coalesce.
-constexpr uint32_t HEAVY_LOAD_16THS = 12;  // max load factor of a heavy hash group in sixteenths (12 = 0.75)
-constexpr uint32_t ITEM_RUN = 8;           // queue positions a workgroup claims per atomic
-constexpr uint32_t ITEM_DENSE = 0x80000000u;
+constexpr uint32_t ITEM_RUN = 8;  // queue positions a workgroup claims per atomic
 
 struct HeavyItem {       // 32 bytes, read with scalar loads
   uint64_t a_start;      // first entry of A's row
   uint64_t out;          // where the group's piece of C's row starts
   uint32_t n_a;          // entries of A's row
-  uint32_t j0;           // chunk range [j0, j1) of the group
-  uint32_t j1_kind;      // j1 | ITEM_DENSE
+  uint32_t j0, j1;       // chunk range [j0, j1) of the group
   uint32_t cnt;          // entries of C the group produces (> 0)
 };
 
-// One wavefront per heavy row: cut the row's chunks into groups and emit one item per non-empty group.  A chunk with
-// more than `hwin` entries is a dense group of its own; the chunks between two dense ones are merged greedily, left to
-// right, while a group stays within `hcap` entries (the hash table's load limit).  The wavefront loads 64 chunk counts
-// at a time; the greedy walk itself is scalar (v_readlane), a few instructions per chunk.
-// FILL = false: count items per queue bucket (hist[2 * j0 + kind]) and the census; FILL = true: write them (cursor =
-// exclusive prefix of hist).
+// One wavefront per heavy row: pack the row's chunks into groups, left to right, while bitmap + values fit the
+// accumulator (8 bytes per 32 columns of span + vsize bytes per entry <= region), and emit one item per group.  The
+// wavefront loads 64 chunk counts at a time; the greedy walk itself is scalar (v_readlane), a few instructions per chunk.
+// FILL = false: count items per queue bucket (hist[j0]) and the census; FILL = true: write them (cursor = exclusive
+// prefix of hist).
 template <bool FILL>
 __global__ __launch_bounds__(256) void heavy_groups_kernel(const uint32_t* __restrict__ rows_list, uint32_t n_rows,
                                                           const uint32_t* __restrict__ hrow_of_row, uint32_t nchunks,
                                                           const uint32_t* __restrict__ hcnt,
                                                           const uint32_t* __restrict__ hoff,
                                                           const uint64_t* __restrict__ a_rp,
-                                                          const uint64_t* __restrict__ c_rp, uint32_t hwin, uint32_t hcap,
+                                                          const uint64_t* __restrict__ c_rp, uint32_t cw_shift,
+                                                          uint32_t vsize, uint32_t region,
                                                           uint32_t* __restrict__ hist_or_cursor,
                                                           HeavyItem* __restrict__ items,
                                                           unsigned long long* __restrict__ census) {
@@ -1122,24 +1052,20 @@ __global__ __launch_bounds__(256) void heavy_groups_kernel(const uint32_t* __res
   const uint32_t* ho = hoff + (uint64_t)hrow_of_row[row] * nchunks;
   const uint64_t a_start = a_rp[row], out_row = c_rp[row];
   const uint32_t n_a = (uint32_t)(a_rp[row + 1] - a_start);
-  unsigned long long nd = 0, nh = 0, ed = 0, eh = 0;
-  auto emit = [&](uint32_t j0, uint32_t j1, uint32_t off0, uint32_t cnt, bool dense) {  // lane 0 only
-    const uint32_t key = 2 * j0 + (dense ? 0u : 1u);
+  const uint32_t word_bytes_per_chunk = ((1u << cw_shift) / 32u) * 8u;
+  unsigned long long ng = 0, ne = 0;
+  auto emit = [&](uint32_t j0, uint32_t j1, uint32_t off0, uint32_t cnt) {  // lane 0 only
     if (FILL) {
-      const uint32_t pos = atomicAdd(&hist_or_cursor[key], 1u);
+      const uint32_t pos = atomicAdd(&hist_or_cursor[j0], 1u);
       HeavyItem it;
-      it.a_start = a_start, it.out = out_row + off0, it.n_a = n_a, it.j0 = j0;
-      it.j1_kind = j1 | (dense ? ITEM_DENSE : 0u), it.cnt = cnt;
+      it.a_start = a_start, it.out = out_row + off0, it.n_a = n_a, it.j0 = j0, it.j1 = j1, it.cnt = cnt;
       items[pos] = it;
     } else {
-      atomicAdd(&hist_or_cursor[key], 1u);
-      if (dense)
-        nd += 1, ed += cnt;
-      else
-        nh += 1, eh += cnt;
+      atomicAdd(&hist_or_cursor[j0], 1u);
+      ng += 1, ne += cnt;
     }
   };
-  uint32_t g_start = 0, g_off = 0, g_cnt = 0;  // the open hash group (uniform)
+  uint32_t g_start = 0, g_off = 0, g_cnt = 0, g_last = 0;  // the open group (uniform); g_last = its last non-empty chunk
   for (uint32_t base = 0; base < nchunks; base += 64) {
     const uint32_t j = base + lane;
     const uint32_t c_l = j < nchunks ? hc[j] : 0u, o_l = j < nchunks ? ho[j] : 0u;
@@ -1149,28 +1075,23 @@ __global__ __launch_bounds__(256) void heavy_groups_kernel(const uint32_t* __res
       if (c == 0) continue;
       const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)o_l, (int)t);
       const uint32_t jj = base + t;
-      if (c > hwin) {  // dense chunk: close the open group, emit the chunk on its own
-        if (g_cnt && lane == 0) emit(g_start, jj, g_off, g_cnt, false);
-        g_cnt = 0;
-        if (lane == 0) emit(jj, jj + 1, o, c, true);
-      } else {
-        if (g_cnt && g_cnt + c > hcap) {
-          if (lane == 0) emit(g_start, jj, g_off, g_cnt, false);
+      if (g_cnt) {
+        const uint64_t need = (uint64_t)(jj + 1 - g_start) * word_bytes_per_chunk + (uint64_t)(g_cnt + c) * vsize;
+        if (need > region) {  // close the open group at its last non-empty chunk
+          if (lane == 0) emit(g_start, g_last + 1, g_off, g_cnt);
           g_cnt = 0;
         }
-        if (g_cnt == 0) g_start = jj, g_off = o;
-        g_cnt += c;
       }
+      if (g_cnt == 0) g_start = jj, g_off = o;
+      g_cnt += c;
+      g_last = jj;
     }
   }
-  if (g_cnt && lane == 0) emit(g_start, nchunks, g_off, g_cnt, false);
-  if (!FILL && lane == 0) {
-    if (nd) atomicAdd(&census[0], nd), atomicAdd(&census[2], ed);
-    if (nh) atomicAdd(&census[1], nh), atomicAdd(&census[3], eh);
-  }
+  if (g_cnt && lane == 0) emit(g_start, g_last + 1, g_off, g_cnt);
+  if (!FILL && lane == 0 && ng) atomicAdd(&census[0], ng), atomicAdd(&census[2], ne);
 }
 
-template <class T, bool USE_BPOS, bool SORT, int TPB, int CWS>
+template <class T, bool USE_BPOS, int TPB, int CWS>
 __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD: 16 wavefronts per CU whatever TPB is
     const uint32_t* __restrict__ a_col, const T* __restrict__ a_val, const uint64_t* __restrict__ b_rp,
     const uint32_t* __restrict__ b_col, const T* __restrict__ b_val, const uint32_t* __restrict__ bpos, uint32_t rows_b,
@@ -1178,30 +1099,24 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
     T* __restrict__ c_val, unsigned long long* __restrict__ gstats, int dbg) {
   constexpr int NW = TPB / 64;
   constexpr int CW_SHIFT = CWS;
-  constexpr uint32_t CW = 1u << CWS, HTSIZE = CW / 2;
-  constexpr uint32_t DCOLS = CW / NW;      // dense columns drained per wavefront
-  constexpr uint32_t HSLOTS = HTSIZE / NW;  // hash slots drained per wavefront
-  static_assert(CW == 16 * TPB && DCOLS == 1024 && HSLOTS == 512, "drain geometry: 16 flag bytes / 8 keys per lane");
-  __shared__ __attribute__((aligned(16))) T acc[CW];
-  __shared__ __attribute__((aligned(16))) uint8_t flags[CW];
+  constexpr uint32_t REGION = heavy_region_bytes(TPB);
+  static_assert((1u << CWS) == 16u * TPB, "chunk width is 16 columns per thread");
+  __shared__ __attribute__((aligned(16))) unsigned char region[REGION];
   __shared__ uint32_t wsum[NW + 1];
   __shared__ uint32_t run_s;
-  static_assert(sizeof(T) * CW >= HTSIZE * (4 + sizeof(T)), "hash table must fit the dense accumulator's LDS");
-  uint32_t* hkeys = (uint32_t*)acc;
-  T* hvals = (T*)((char*)acc + HTSIZE * 4);
+  RankWord* words = (RankWord*)region;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4* f4 = (u32x4*)flags;
-  u32x4* a4 = (u32x4*)acc;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // phase timers of this workgroup (thread 0 only, SPAM_DBG_HEAVY=32), cycles: [0] prefetch issue, [1..4] wave 0's product
-  // rounds: search + load issue, load wait, upserts, number of rounds; [5] wait at the products barrier, [6] drain count +
-  // barrier, [7] drain, [8] closing barrier, [9] items
-  __shared__ unsigned long long wg_stat[11];
-  if (threadIdx.x < 11) wg_stat[threadIdx.x] = 0;
+  // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is uniform over a wavefront, and everything derived
+  // from it — piece dealing, word slices — would otherwise be emitted as divergent vector code)
+  const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // phase timers of this workgroup (thread 0 only, SPAM_DBG_HEAVY=32), cycles: [0] prefetch issue, [1] pass 1 (wave 0),
+  // [2] barrier after pass 1, [3] prefix step, [4] pass 2 (wave 0), [5] barrier after pass 2, [6] drain, [7] closing
+  // barrier, [8] items
+  __shared__ unsigned long long wg_stat[9];
+  if (threadIdx.x < 9) wg_stat[threadIdx.x] = 0;
   unsigned long long t0 = 0;
   const bool timing = (dbg & 32) && threadIdx.x == 0;
-  f4[threadIdx.x] = (u32x4)(0u);  // TPB x 16 = CW flags
-  for (int i = threadIdx.x; i < (int)(sizeof(T) * CW / 16); i += TPB) a4[i] = (u32x4)(0u);
+  for (int i = threadIdx.x; i < (int)(REGION / 16); i += TPB) ((u32x4*)region)[i] = (u32x4)(0u);
   if (threadIdx.x == 0) run_s = atomicAdd(queue, ITEM_RUN);
   __syncthreads();
   // the workgroup's item sequence: runs of ITEM_RUN consecutive queue positions; `pos` walks the current run
@@ -1213,14 +1128,9 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
     return run_next < n_items ? run_next + (q - ITEM_RUN) : 0xFFFFFFFFu;  // (ahead <= 3: the next run is known from pos 1 on)
   };
   auto load_item = [&](uint32_t idx, HeavyItem& it) {
-    it.n_a = 0, it.cnt = 0, it.j0 = 0, it.j1_kind = 0, it.a_start = 0, it.out = 0;
+    it.n_a = 0, it.cnt = 0, it.j0 = 0, it.j1 = 0, it.a_start = 0, it.out = 0;
     if (idx < n_items) it = items[idx];  // uniform address: scalar loads
   };
-  // The first 64 entries of A's row (in a sorted row the lowest columns: R-MAT's hub vertices, whose B rows hold most of
-  // the item's products) are SHARED: every wavefront holds all of them, lane l entry l, and multiplies its 1/NW slice of
-  // each segment — otherwise the wavefront owning the hub runs several times longer than the others.  The entries
-  // after them are OWNED: thread (wave w, lane l) owns entry 64 + l * NW + w when the row has at most 64 + TPB entries
-  // (registers for the whole item); longer rows stream them in 64-entry batches per wavefront.
   auto fetch_entry = [&](const HeavyItem& it, uint32_t& ks, T& as, uint32_t& ko, T& ao) {
     ks = 0xFFFFFFFFu, ko = 0xFFFFFFFFu, as = T(0), ao = T(0);
     if (lane < it.n_a) {
@@ -1254,202 +1164,153 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
   load_item(item_index(2), it_nn);
   fetch_entry(it_c, ks_c, as_c, ko_c, ao_c);
   fetch_entry(it_n, ks_n, as_n, ko_n, ao_n);
-  fetch_range(it_c.j0, it_c.j1_kind & ~ITEM_DENSE, ks_c, los_c, lens_c);
-  fetch_range(it_c.j0, it_c.j1_kind & ~ITEM_DENSE, ko_c, loo_c, leno_c);
-  // LDS starts dense-clean (all zero); make it hash-clean if the first item is a hash group
-  if (it_c.cnt && !(it_c.j1_kind & ITEM_DENSE)) {
-    for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += TPB) a4[i] = (u32x4)(EMPTY_KEY);
-  }
-  __syncthreads();
+  fetch_range(it_c.j0, it_c.j1, ks_c, los_c, lens_c);
+  fetch_range(it_c.j0, it_c.j1, ko_c, loo_c, leno_c);
   while (it_c.cnt) {  // cnt == 0 marks the end of the queue
     if (timing) t0 = clock64();
     // the run after this one is claimed while the first item of a run is processed and read at its end
     unsigned int claimed = 0;
     if (pos == 0 && threadIdx.x == 0) claimed = atomicAdd(queue, ITEM_RUN);
-    const uint32_t j0 = it_c.j0, j1 = it_c.j1_kind & ~ITEM_DENSE;
-    const bool dense = (it_c.j1_kind & ITEM_DENSE) != 0;
+    const uint32_t j0 = it_c.j0, j1 = it_c.j1;
     const uint32_t c0 = j0 << CW_SHIFT, cspan = (j1 - j0) << CW_SHIFT;
+    const uint32_t nwords = cspan >> 5;                       // multiple of 16 * TPB / 32 = TPB / 2: a whole number of
+    T* vals = (T*)(region + (size_t)nwords * sizeof(RankWord));  // 64-word steps for every wavefront
     // prefetch: B-split lookups of the next item (its entries were requested an item ago), entries of the one after
-    fetch_range(it_n.j0, it_n.j1_kind & ~ITEM_DENSE, ks_n, los_n, lens_n);
-    fetch_range(it_n.j0, it_n.j1_kind & ~ITEM_DENSE, ko_n, loo_n, leno_n);
+    fetch_range(it_n.j0, it_n.j1, ks_n, los_n, lens_n);
+    fetch_range(it_n.j0, it_n.j1, ko_n, loo_n, leno_n);
     load_item(item_index(3), it_n3);
     fetch_entry(it_nn, ks_nn, as_nn, ko_nn, ao_nn);
     if (timing) {
       const unsigned long long t1 = clock64();
-      wg_stat[0] += t1 - t0, wg_stat[10] += 1;
+      wg_stat[0] += t1 - t0, wg_stat[8] += 1;
       t0 = t1;
     }
-    unsigned long long* wstat = timing ? wg_stat + 1 : nullptr;
-    // ---- products: every wavefront on its own ---------------------------------------------------------------
-    wave_products<T, HTSIZE - 1>(los_c, lens_c, as_c, true, NW, wave, b_col, b_val, c0, cspan, dense, acc, flags, hkeys, hvals, wstat);
-    if (it_c.n_a <= (uint32_t)(64 + TPB)) {
-      if (it_c.n_a > 64)  // (uniform)
-        wave_products<T, HTSIZE - 1>(loo_c, leno_c, ao_c, false, NW, wave, b_col, b_val, c0, cspan, dense, acc, flags, hkeys, hvals, wstat);
-    } else {
-      // streamed A row: after the shared head, wavefront w takes the 64-entry batches w, w + NW, ...; while batch i is
-      // multiplied the B-split lookups of batch i + 1 and the entries of batch i + 2 are in flight
-      const uint64_t ps = it_c.a_start + 64, pe = it_c.a_start + it_c.n_a;
-      const uint64_t nb = ((uint64_t)it_c.n_a - 64 + 63) >> 6;
-      auto s_entry = [&](uint64_t bb, uint32_t& k, T& a) {
-        const uint64_t p = ps + (bb << 6) + lane;
-        k = 0xFFFFFFFFu, a = T(0);
-        if (bb < nb && p < pe) {
-          k = a_col[p];
-          a = a_val[p];
+    // ---- both passes over the item's products: every wavefront on its own ------------------------------------
+    auto all_products = [&](auto pass_tag) {
+      constexpr int PASS = decltype(pass_tag)::value;
+      wave_products<T, PASS>(los_c, lens_c, as_c, true, NW, wave, b_col, b_val, c0, cspan, words, vals);
+      if (it_c.n_a <= (uint32_t)(64 + TPB)) {
+        if (it_c.n_a > 64)  // (uniform)
+          wave_products<T, PASS>(loo_c, leno_c, ao_c, false, NW, wave, b_col, b_val, c0, cspan, words, vals);
+      } else {
+        // streamed A row: after the shared head, wavefront w takes the 64-entry batches w, w + NW, ...; while batch i
+        // is multiplied the B-split lookups of batch i + 1 and the entries of batch i + 2 are in flight
+        const uint64_t ps = it_c.a_start + 64, pe = it_c.a_start + it_c.n_a;
+        const uint64_t nb = ((uint64_t)it_c.n_a - 64 + 63) >> 6;
+        auto s_entry = [&](uint64_t bb, uint32_t& k, T& a) {
+          const uint64_t p = ps + (bb << 6) + lane;
+          k = 0xFFFFFFFFu, a = T(0);
+          if (bb < nb && p < pe) {
+            k = a_col[p];
+            if (PASS == 2) a = a_val[p];
+          }
+        };
+        uint32_t k1, k2, lo1, len1;
+        T a1, a2;
+        s_entry(wave, k1, a1);
+        s_entry(wave + NW, k2, a2);
+        fetch_range(j0, j1, k1, lo1, len1);
+        for (uint64_t b = wave; b < nb; b += NW) {
+          const uint32_t lo_b = lo1, len_b = len1;
+          const T a_b = a1;
+          fetch_range(j0, j1, k2, lo1, len1);
+          a1 = a2;
+          s_entry(b + 2 * NW, k2, a2);
+          wave_products<T, PASS>(lo_b, len_b, a_b, false, NW, wave, b_col, b_val, c0, cspan, words, vals);
         }
-      };
-      uint32_t k1, k2, lo1, len1;
-      T a1, a2;
-      s_entry(wave, k1, a1);
-      s_entry(wave + NW, k2, a2);
-      fetch_range(j0, j1, k1, lo1, len1);
-      for (uint64_t b = wave; b < nb; b += NW) {
-        const uint32_t lo_b = lo1, len_b = len1;
-        const T a_b = a1;
-        fetch_range(j0, j1, k2, lo1, len1);
-        a1 = a2;
-        s_entry(b + 2 * NW, k2, a2);
-        wave_products<T, HTSIZE - 1>(lo_b, len_b, a_b, false, NW, wave, b_col, b_val, c0, cspan, dense, acc, flags, hkeys, hvals, wstat);
       }
-    }
-    if (timing) t0 = clock64();
-    __syncthreads();  // all products of the group are in LDS
-    const uint64_t out = it_c.out;
-    const uint32_t cnt = it_c.cnt;
-    const bool next_dense = it_n.cnt ? (it_n.j1_kind & ITEM_DENSE) != 0 : dense;
+    };
+    all_products(std::integral_constant<int, 1>{});
     if (timing) {
       const unsigned long long t1 = clock64();
-      wg_stat[6] += t1 - t0;
+      wg_stat[1] += t1 - t0;
       t0 = t1;
     }
-    if (dense) {
-      // column order: wavefront w owns columns [w * DCOLS, (w + 1) * DCOLS), 64 consecutive columns per step
-      const u32x4 fw = f4[wave * (DCOLS / 16) + lane];
-      uint32_t n = __popc(fw.x) + __popc(fw.y) + __popc(fw.z) + __popc(fw.w);
-      n = wave_total_u32(n);
-      if (lane == 0) wsum[wave] = n;
-      __syncthreads();
-      if (timing) {
-        const unsigned long long t1 = clock64();
-        wg_stat[7] += t1 - t0;
-        t0 = t1;
-      }
-      uint32_t run = 0;
-#pragma unroll
-      for (int i = 0; i < NW; ++i) run += (i < (int)wave) ? wsum[i] : 0u;
-      if (n) {  // (uniform per wavefront)
-        const uint64_t lt = (1ull << lane) - 1ull;
-        const uint8_t* fl = flags + wave * DCOLS + lane;
-#pragma unroll 4
-        for (int s = 0; s < (int)(DCOLS / 64); ++s) {
-          const bool occ = fl[64 * s] != 0;
-          const uint64_t m = __ballot(occ);
-          if (occ) {
-            const uint32_t c = wave * DCOLS + 64 * s + lane;
-            const uint64_t o = out + run + __popcll(m & lt);
-            c_col[o] = c0 + c;
-            c_val[o] = acc[c];
-            acc[c] = T(0);
-          }
-          run += (uint32_t)__popcll(m);
-        }
-        f4[wave * (DCOLS / 16) + lane] = (u32x4)(0u);
-      }
-      if (!next_dense) {
-        // hash-clean for the next item: the key region is the first HTSIZE * 4 bytes of acc = the slices of the first
-        // NW / 4 wavefronts, each of which converts the slice it has just drained
-        if (wave * DCOLS * sizeof(T) < HTSIZE * 4) {
-          u32x4* mine4 = (u32x4*)((char*)acc + wave * DCOLS * sizeof(T));
-          const uint32_t bytes = (uint32_t)(DCOLS * sizeof(T));
-          const uint32_t lim = (uint32_t)(HTSIZE * 4 - wave * DCOLS * sizeof(T));
-          for (uint32_t i = lane; i < (bytes < lim ? bytes : lim) / 16; i += 64) mine4[i] = (u32x4)(EMPTY_KEY);
-        }
-      }
-    } else if (SORT) {
-      // B2 = true (mul_hash.rs:164-175): bitonic sort of the whole table by key (u32::MAX = empty sorts
-      // last), after which the group's entries are slots [0, cnt)
-      for (uint32_t k = 2; k <= HTSIZE; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-          for (uint32_t i = threadIdx.x; i < HTSIZE; i += TPB) {
-            const uint32_t l = i ^ j;
-            if (l > i) {
-              const uint32_t ki = hkeys[i], kl = hkeys[l];
-              if ((ki > kl) == ((i & k) == 0)) {
-                hkeys[i] = kl;
-                hkeys[l] = ki;
-                const T t = hvals[i];
-                hvals[i] = hvals[l];
-                hvals[l] = t;
-              }
-            }
-          }
-          __syncthreads();
-        }
-      }
-      for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
-        c_col[out + i] = hkeys[i];
-        c_val[out + i] = hvals[i];
-        hkeys[i] = EMPTY_KEY;
-        hvals[i] = T(0);
-      }
-      if (next_dense) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < (int)(HTSIZE * 4 / 16); i += TPB) a4[i] = (u32x4)(0u);
-      }
-    } else {
-      // slot order (map.rs:59-63): wavefront w owns slots [w * HSLOTS, (w + 1) * HSLOTS), 64 consecutive slots per step
-      uint32_t kk[HSLOTS / 64];
+    __syncthreads();  // the bitmap is complete
+    if (timing) {
+      const unsigned long long t1 = clock64();
+      wg_stat[2] += t1 - t0;
+      t0 = t1;
+    }
+    // ---- prefix step: wavefront w owns the words [w * wpw, (w + 1) * wpw), 64 consecutive words per step ----------
+    const uint32_t wpw = nwords / NW;  // nwords is a multiple of 64 * NW / 8 ... see below: handled with a tail check
+    {
       uint32_t n = 0;
-#pragma unroll
-      for (int s = 0; s < (int)(HSLOTS / 64); ++s) {
-        kk[s] = hkeys[wave * HSLOTS + 64 * s + lane];
-        n += kk[s] != EMPTY_KEY;
-      }
-      n = wave_total_u32(n);
+      for (uint32_t i = wave * wpw + lane; i < (wave + 1) * wpw; i += 64) n += __popc(words[i].bits);
+      n = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(n), 63);
       if (lane == 0) wsum[wave] = n;
-      __syncthreads();
-      if (timing) {
-        const unsigned long long t1 = clock64();
-        wg_stat[7] += t1 - t0;
-        t0 = t1;
-      }
+    }
+    __syncthreads();
+    {
       uint32_t run = 0;
 #pragma unroll
       for (int i = 0; i < NW; ++i) run += (i < (int)wave) ? wsum[i] : 0u;
-      if (n) {
-        const uint64_t lt = (1ull << lane) - 1ull;
-        T vv[HSLOTS / 64];
-#pragma unroll
-        for (int s = 0; s < (int)(HSLOTS / 64); ++s) vv[s] = hvals[wave * HSLOTS + 64 * s + lane];  // all reads in flight
-#pragma unroll
-        for (int s = 0; s < (int)(HSLOTS / 64); ++s) {
-          const bool occ = kk[s] != EMPTY_KEY;
-          const uint64_t m = __ballot(occ);
-          if (occ) {
-            const uint32_t slot = wave * HSLOTS + 64 * s + lane;
-            const uint64_t o = out + run + __popcll(m & lt);
-            c_col[o] = kk[s];
-            c_val[o] = vv[s];
-            hvals[slot] = T(0);
-            if (!next_dense) hkeys[slot] = EMPTY_KEY;
-          }
-          run += (uint32_t)__popcll(m);
-        }
+      for (uint32_t i0 = wave * wpw; i0 < (wave + 1) * wpw; i0 += 64) {  // (uniform trip count; wpw may not be a multiple of 64)
+        const uint32_t i = i0 + lane;
+        const bool in = i < (wave + 1) * wpw;
+        const uint32_t pc = in ? __popc(words[i].bits) : 0u;
+        const uint32_t inc = wave_incl_scan_u32(pc);
+        if (in) words[i].prefix = run + inc - pc;
+        run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
       }
-      if (next_dense) {  // dense-clean for the next item: this wavefront's key slots become zeros
-        u32x4* mine4 = (u32x4*)(hkeys + wave * HSLOTS);
-        for (uint32_t i = lane; i < HSLOTS * 4 / 16; i += 64) mine4[i] = (u32x4)(0u);
+    }
+    __syncthreads();  // every word knows its first output position
+    if (timing) {
+      const unsigned long long t1 = clock64();
+      wg_stat[3] += t1 - t0;
+      t0 = t1;
+    }
+    all_products(std::integral_constant<int, 2>{});
+    if (timing) {
+      const unsigned long long t1 = clock64();
+      wg_stat[4] += t1 - t0;
+      t0 = t1;
+    }
+    __syncthreads();  // all products of the group are in LDS
+    if (timing) {
+      const unsigned long long t1 = clock64();
+      wg_stat[5] += t1 - t0;
+      t0 = t1;
+    }
+    // ---- drain: the values are the row piece in column order; the columns are expanded from the bitmap -----------
+    const uint64_t out = it_c.out;
+    const uint32_t cnt = it_c.cnt;
+    for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
+      c_val[out + i] = vals[i];
+      vals[i] = T(0);
+    }
+    // columns: every lane expands its own words (a loop over the word's set bits; adjacent lanes hold adjacent words, so
+    // the stores of one step land in one stretch of C).  Two alternatives measured slower: 32 lanes per word with the
+    // word broadcast by ds_bpermute (30.8 k cycles per item against 11.7 k) or re-read from LDS (16.5 k).
+    for (uint32_t i0 = wave * wpw; i0 < (wave + 1) * wpw; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      if (i < (wave + 1) * wpw) {
+        const RankWord w = words[i];
+        if (w.bits) {
+          uint32_t bits = w.bits;
+          uint64_t o = out + w.prefix;
+          const uint32_t cbase = c0 + (i << 5);
+          while (bits) {
+            c_col[o++] = cbase + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+          }
+        }
+        if (w.bits | w.prefix) {
+          RankWord z;
+          z.prefix = 0, z.bits = 0;
+          words[i] = z;
+        }
       }
     }
     if (pos == 0 && threadIdx.x == 0) run_s = claimed;
     if (timing) {
       const unsigned long long t1 = clock64();
-      wg_stat[8] += t1 - t0;
+      wg_stat[6] += t1 - t0;
       t0 = t1;
     }
-    __syncthreads();  // LDS is clean again (in the next item's mode); the claimed run is visible
+    __syncthreads();  // LDS is all zero again; the claimed run is visible
     if (pos == 0) run_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_s);
-    if (timing) wg_stat[9] += clock64() - t0;
+    if (timing) wg_stat[7] += clock64() - t0;
     // advance the sequence and shift the prefetch pipeline
     if (++pos == ITEM_RUN) {
       pos = 0;
@@ -1462,7 +1323,7 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
     ks_n = ks_nn, as_n = as_nn, ko_n = ko_nn, ao_n = ao_nn;
   }
   if (timing)
-    for (int i = 0; i < 11; ++i) atomicAdd(&gstats[4 + i], wg_stat[i]);
+    for (int i = 0; i < 9; ++i) atomicAdd(&gstats[4 + i], wg_stat[i]);
 }
 
 // ---- B2: sort each row by column (mul_hash.rs:164-175) ----------------------------------------------
@@ -2316,20 +2177,20 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     const char* dbg_env = getenv("SPAM_DBG_HEAVY");  // 32: print in-kernel phase timers (results unaffected)
     const int dbg_heavy = dbg_env ? atoi(dbg_env) : 0;
     const uint32_t* hl = L + (uint64_t)(NNUM - 1) * rows;
-    // work items: one per (row, chunk group), bucketed by first chunk (dense before hash) = the queue order
-    const uint32_t nbuckets = 2 * p->nchunks;
-    const uint32_t htsize = (1u << p->cw_shift) / 2, hwin = HEAVY_LOAD_16THS * htsize / 32, hcap = 2 * hwin;
+    // work items: one per (row, chunk group), bucketed by first chunk = the queue order
+    const uint32_t nbuckets = p->nchunks;
+    const int tpb = (1 << p->cw_shift) / 16;
     DevBuf gst, hist, items;
     SPAM_TRY(gst.alloc(256));
     SPAM_TRY(hist.alloc(((uint64_t)nbuckets + 2) * 4));
     SPAM_HIP_TRY(hipMemsetAsync(gst.p, 0, 256, s));
     SPAM_HIP_TRY(hipMemsetAsync(hist.p, 0, ((uint64_t)nbuckets + 2) * 4, s));
-    unsigned long long* census = gst.as<unsigned long long>();           // [0..3] census, [4..10] phase timers
+    unsigned long long* census = gst.as<unsigned long long>();           // [0] groups, [2] entries, [4..12] phase timers
     uint32_t* queue = (uint32_t*)(gst.as<unsigned long long>() + 16);    // work queue head
     const unsigned gg = (unsigned)(((uint64_t)n_hnum * 64 + 255) / 256);
     heavy_groups_kernel<false><<<gg, 256, 0, s>>>(hl, n_hnum, p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hcnt.as<uint32_t>(),
-                                                  p->hoff.as<uint32_t>(), a->row_ptr, crp, hwin, hcap, hist.as<uint32_t>(),
-                                                  nullptr, census);
+                                                  p->hoff.as<uint32_t>(), a->row_ptr, crp, (uint32_t)p->cw_shift, (uint32_t)sizeof(T),
+                                                  heavy_region_bytes(tpb), hist.as<uint32_t>(), nullptr, census);
     SPAM_CHECK_LAUNCH();
     bucket_scan_kernel<<<1, 1024, 0, s>>>(hist.as<uint32_t>(), nbuckets);
     SPAM_CHECK_LAUNCH();
@@ -2338,12 +2199,12 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     SPAM_HIP_TRY(hipStreamSynchronize(s));
     SPAM_TRY(items.alloc((uint64_t)std::max<uint32_t>(n_items, 1) * sizeof(HeavyItem)));
     heavy_groups_kernel<true><<<gg, 256, 0, s>>>(hl, n_hnum, p->hrow_of_row.as<uint32_t>(), p->nchunks, p->hcnt.as<uint32_t>(),
-                                                 p->hoff.as<uint32_t>(), a->row_ptr, crp, hwin, hcap, hist.as<uint32_t>(),
-                                                 items.as<HeavyItem>(), census);
+                                                 p->hoff.as<uint32_t>(), a->row_ptr, crp, (uint32_t)p->cw_shift, (uint32_t)sizeof(T),
+                                                 heavy_region_bytes(tpb), hist.as<uint32_t>(), items.as<HeavyItem>(), census);
     SPAM_CHECK_LAUNCH();
-#define SPAM_NUM_HEAVY_G(BPOS_, SORT_, TPB_, CWS_)                                                                   \
+#define SPAM_NUM_HEAVY_G(BPOS_, TPB_, CWS_)                                                                          \
   do {                                                                                                               \
-    auto kern = num_heavy_kernel<T, BPOS_, SORT_, TPB_, CWS_>;                                                       \
+    auto kern = num_heavy_kernel<T, BPOS_, TPB_, CWS_>;                                                              \
     int per_cu = 0;                                                                                                  \
     SPAM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, TPB_, 0));                              \
     if (per_cu < 1) per_cu = 1;                                                                                      \
@@ -2354,21 +2215,17 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
                                BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, items.as<HeavyItem>(),   \
                                n_items, queue, cc, cv, census, dbg_heavy);                                           \
   } while (0)
-#define SPAM_NUM_HEAVY(BPOS_, SORT_)                                                        \
+#define SPAM_NUM_HEAVY(BPOS_)                                                               \
   do {                                                                                      \
     if (p->cw_shift == CW_SHIFT_256)                                                        \
-      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 256, CW_SHIFT_256);                                    \
+      SPAM_NUM_HEAVY_G(BPOS_, 256, CW_SHIFT_256);                                           \
     else if (p->cw_shift == CW_SHIFT_512)                                                   \
-      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 512, CW_SHIFT_512);                                    \
+      SPAM_NUM_HEAVY_G(BPOS_, 512, CW_SHIFT_512);                                           \
     else                                                                                    \
-      SPAM_NUM_HEAVY_G(BPOS_, SORT_, 1024, CW_SHIFT_1024);                                  \
+      SPAM_NUM_HEAVY_G(BPOS_, 1024, CW_SHIFT_1024);                                         \
   } while (0)
     if (n_items) {
-      if (p->use_bpos) {
-        if (sort_rows == 1) SPAM_NUM_HEAVY(true, true); else SPAM_NUM_HEAVY(true, false);
-      } else {
-        if (sort_rows == 1) SPAM_NUM_HEAVY(false, true); else SPAM_NUM_HEAVY(false, false);
-      }
+      if (p->use_bpos) SPAM_NUM_HEAVY(true); else SPAM_NUM_HEAVY(false);
     }
 #undef SPAM_NUM_HEAVY
 #undef SPAM_NUM_HEAVY_G
@@ -2378,13 +2235,12 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
     SPAM_HIP_TRY(hipMemcpyAsync(hg, gst.p, 128, hipMemcpyDeviceToHost, s));
     SPAM_HIP_TRY(hipStreamSynchronize(s));
     if (dbg_heavy & 32) {
-      const double ni = (double)(hg[14] ? hg[14] : 1);
-      fprintf(stderr, "[spam dbg] heavy numeric, cycles per item (thread 0 of every workgroup): prefetch issue %.0f | wave 0: long pieces %.0f, "
-              "short segments: search + load issue %.0f, load wait %.0f, upserts %.0f (%.2f rounds) | products barrier %.0f | drain count + "
-              "barrier %.0f | drain %.0f | closing barrier %.0f; %u rows, %u items\n", hg[4] / ni, hg[9] / ni, hg[5] / ni, hg[6] / ni,
-              hg[7] / ni, hg[8] / ni, hg[10] / ni, hg[11] / ni, hg[12] / ni, hg[13] / ni, n_hnum, n_items);
+      const double ni = (double)(hg[12] ? hg[12] : 1);
+      fprintf(stderr, "[spam dbg] heavy numeric, cycles per item (thread 0 of every workgroup): prefetch issue %.0f | pass 1 %.0f | barrier %.0f | "
+              "prefix step %.0f | pass 2 %.0f | barrier %.0f | drain %.0f | closing barrier %.0f; %u rows, %u items\n", hg[4] / ni, hg[5] / ni,
+              hg[6] / ni, hg[7] / ni, hg[8] / ni, hg[9] / ni, hg[10] / ni, hg[11] / ni, n_hnum, n_items);
     }
-    st.heavy_dense_groups = hg[0], st.heavy_hash_groups = hg[1], st.heavy_dense_nnz = hg[2], st.heavy_hash_nnz = hg[3];
+    st.heavy_dense_groups = hg[0], st.heavy_hash_groups = 0, st.heavy_dense_nnz = hg[2], st.heavy_hash_nnz = 0;
   }
   if (sort_rows == 2 && n_hnum) {
     // long rows: first-occurrence positions chunk by chunk, then the reference-layout table in HBM
