@@ -109,6 +109,9 @@ class CsrMatrix {
   CsrMatrix<T, true> operator+(const CsrMatrix& rhs) const { return ewise(rhs, 0); }
   CsrMatrix<T, true> operator-(const CsrMatrix& rhs) const { return ewise(rhs, 1); }
 
+  // the SpMV analysis on the uploaded copy (spam_spmv_prepare): worth it when the matrix is multiplied many times
+  void spmv_prepare() const { check(spam_spmv_prepare(const_cast<spam_csr*>(device()), nullptr)); }
+
   // y = A x (absent upstream; mul_hash with an n x 1 right-hand side)
   std::vector<T> spmv(const std::vector<T>& x) const {
     if (x.size() != cols_) throw Panic(SPAM_E_INVALID, "x.len() != cols");

@@ -17,8 +17,11 @@
  * status and records a message for spam_last_error(); the Rust shim turns non-zero into panic!().
  * Unlike the reference, A.cols == B.rows is checked up front.
  *
- * Threading: handles may be read concurrently; calls that create or free a handle, and the global
- * device/stream selection, must not race.  One process drives one GPU (one rank per GPU under RCCL).
+ * Threading: a handle may be used by several host threads at once for SpMV / SpGEMM / downloads (the lazily
+ * built SpMV tile map is created under a per-handle lock); spam_spmv_prepare, spam_csr_values_changed,
+ * spam_csr_sort_rows and spam_csr_free need exclusive use of the handle.  The stream selection is process-global and
+ * the device allocator recycles blocks without stream ordering: use ONE stream per process (spam_hip_set_stream once,
+ * before any other call).  One process drives one GPU (one rank per GPU under RCCL).
  */
 #ifndef SPAM_HIP_H
 #define SPAM_HIP_H
@@ -125,13 +128,26 @@ int spam_csr_add(const spam_csr* a, const spam_csr* b, int subtract, spam_csr** 
 int spam_spmv_f64(const spam_csr* a, const double* x_host, double* y_host); /* host slices (&[T] -> Vec<T>) */
 int spam_spmv_f32(const spam_csr* a, const float* x_host, float* y_host);
 int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y); /* device-resident vectors, asynchronous */
-/* What the SpMV analysis of this matrix decided (valid after the first SpMV on the handle): number of columns in the
+/* The analysis step (CSR-adaptive's row binning; here: row -> tile map, hot-column table, XCD-sliced structure), done
+ * ONCE per matrix and never inside spam_spmv_*: reads the SPAM_SPMV_* environment knobs, synchronises with the host,
+ * and — when the matrix qualifies for the XCD-sliced path — times three SpMVs of either path on d_x (NULL: a vector of
+ * ones) and keeps the faster (the sliced one must win by 3 %).  The choice fixes the summation order of later SpMVs on
+ * this handle.  A handle that was never prepared multiplies through the plain tile path without hot-column table: its
+ * first SpMV only adds one small kernel (no analysis, no timing), so a one-shot y = A x costs one pass over A.
+ * Prepare again after changing the knobs; not to be called while SpMVs on this handle are being queued elsewhere. */
+int spam_spmv_prepare(spam_csr* a, const void* d_x);
+/* The SpMV plan of a prepared handle may hold private copies of the matrix VALUES (the XCD-sliced structure stores the
+ * long rows again, slab by slab).  After updating vals in place — allowed for arrays wrapped by spam_csr_from_device /
+ * from_sorted_coo — call this to gather them again (asynchronous, a few ms for 160 M entries; no new analysis).  The
+ * STRUCTURE (row_ptr, col_idx) of a handle must never change: wrap a new handle instead. */
+int spam_csr_values_changed(spam_csr* a);
+/* What the SpMV analysis of this matrix decided (valid after spam_spmv_prepare): number of columns in the
  * L2-resident hot table (0 = disabled), the share of the entries they cover, and the number of nnz tiles. */
 int spam_spmv_plan_info(const spam_csr* a, uint64_t* hot_columns, double* hot_cover, uint64_t* tiles);
-/* XCD-sliced mode (valid after the first SpMV): when x is larger than one XCD's L2 and eight per-XCD x-tables cover
+/* XCD-sliced mode (valid after spam_spmv_prepare): when x is larger than one XCD's L2 and eight per-XCD x-tables cover
  * clearly more gathers than one, the analysis deals the most referenced columns over 8 slabs, stores the rows of
  * >= long_min entries as 8 slab CSRs (+ 8 partial y vectors, added in slab order) and keeps the shorter rows in a
- * residual CSR; the first SpMV times both paths on the caller's x and keeps the faster one.  *active = 1 when the
+ * residual CSR; spam_spmv_prepare times both paths and keeps the faster one.  *active = 1 when the
  * sliced path won; the other outputs describe it (rows / entries in the slabs, table slots per XCD, slots also held
  * in LDS, share of the gathers covered by the 8 tables / by one table, the two timings in ms).  Environment:
  * SPAM_SPMV_SLICED = 0 never, 1 decide (default), 2 always. */

@@ -131,6 +131,15 @@ class DeviceCsr:
         return offsets
 
     # -- products -----------------------------------------------------------------------------
+    def spmv_prepare(self, x_ptr: int | None = None):
+        """The SpMV analysis (row -> tile map, hot-column table, XCD-sliced structure and the timed choice between the
+        two paths on the device vector at ``x_ptr``, or on ones).  Once per matrix; ``spmv_dev`` never analyses."""
+        check(_lib.load().spam_spmv_prepare(self._h, C.c_void_p(x_ptr) if x_ptr else None))
+
+    def values_changed(self):
+        """Tell the handle that ``vals`` was updated in place (the prepared SpMV plan may hold copies)."""
+        check(_lib.load().spam_csr_values_changed(self._h))
+
     def spmv_dev(self, x_ptr: int, y_ptr: int):
         check(_lib.load().spam_spmv_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
 
@@ -328,6 +337,10 @@ class CsrMatrix:
 
     __matmul__ = __mul__
 
-    def spmv(self, x) -> np.ndarray:
-        """y = A x (absent upstream; defined as mul_hash with an n x 1 rhs)."""
-        return self.device().spmv(np.asarray(x))
+    def spmv(self, x, prepare: bool = False) -> np.ndarray:
+        """y = A x (absent upstream; defined as mul_hash with an n x 1 rhs).  ``prepare`` runs the
+        SpMV analysis on the (cached) device copy first — worth it when the matrix is multiplied many times."""
+        d = self.device()
+        if prepare:
+            d.spmv_prepare()
+        return d.spmv(np.asarray(x))

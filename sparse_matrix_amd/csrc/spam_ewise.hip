@@ -112,10 +112,8 @@ static int private_sorted_copy(const spam_csr* m, spam_csr** out) {
   // upload-equivalent deep copy on the device, then sort its rows
   spam_csr* c = new (std::nothrow) spam_csr();
   if (!c) return set_error(SPAM_E_OOM, "host allocation failed");
-  *c = *m;
-  c->spmv_plan = nullptr;
-  c->row_ptr32 = nullptr;
-  c->owns_row_ptr = c->owns_row_ptr32 = c->owns_col_val = false;
+  c->rows = m->rows, c->cols = m->cols, c->nnz = m->nnz, c->dtype = m->dtype, c->is_sorted = m->is_sorted;
+  c->row_ptr = m->row_ptr;  // borrowed; col_idx / vals are replaced by private copies below
   DevBuf ci, va;
   hipStream_t s = stream();
   const size_t vs = dtype_size(m->dtype);

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <new>
 
 #include "../../include/spam_hip.h"
@@ -93,7 +94,8 @@ struct spam_csr {
   uint32_t* col_idx = nullptr;    // u32[nnz]
   void* vals = nullptr;           // T[nnz]
   bool owns_row_ptr = false, owns_row_ptr32 = false, owns_col_val = false;
-  spam::SpmvPlan* spmv_plan = nullptr;  // built on first SpMV (row -> tile map), property of row_ptr only
+  spam::SpmvPlan* spmv_plan = nullptr;  // built by spam_spmv_prepare or on the first SpMV; read-only afterwards
+  std::mutex plan_mu;                   // serialises its construction (handles may be used from several host threads)
 };
 
 namespace spam {

@@ -41,6 +41,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "spam_internal.hpp"
 
@@ -49,7 +50,25 @@ namespace spam {
 struct SlicedPlan;
 static void sliced_plan_free(SlicedPlan* q);
 
+// Tuning knobs, read from the environment ONCE per plan (spam_spmv_prepare / the first SpMV on a handle).
+struct SpmvKnobs {
+  int npt = 16;          // SPAM_SPMV_NPT        entries per thread of the plain tile kernel (8 / 16)
+  int nt = 1;            // SPAM_SPMV_NT         non-temporal ja / a stream
+  int hot = 2;           // SPAM_SPMV_HOT        0 off, 1 per-lane base select, 2 cold gathers non-temporal
+  int hot_kb = 3072;     // SPAM_SPMV_HOT_KB     hot-column table budget (of the 4 MB L2 per XCD)
+  int sliced = 1;        // SPAM_SPMV_SLICED     0 never, 1 decide (timed in spam_spmv_prepare), 2 always
+  int slice_kb = 3072;   // SPAM_SPMV_SLICE_KB   table bytes per XCD
+  int lds_kb = -1;       // SPAM_SPMV_LDS_KB     hottest slots copied to LDS (-1 decide, 0 never)
+  int l0_kb = 16;        // SPAM_SPMV_L0_KB      contiguous hottest level without LDS
+  int long_min = 0;      // SPAM_SPMV_LONG       rows with at least this many entries go to the slabs (0: model)
+  int tpb = 256, snpt = 8, wgs = 16, pipe = 1;  // SPAM_SPMV_SLICED_TPB / _NPT / _WGS, SPAM_SPMV_PIPE
+  int prof = 0;          // SPAM_SPMV_PROF       1 in-kernel phase timers, 2 skip phase 2 (diagnostics, wrong results)
+};
+
 struct SpmvPlan {
+  std::mutex mu;                    // serialises plan construction (first SpMV / prepare / values_changed) on a handle
+  bool prepared = false;            // spam_spmv_prepare ran: hot table and XCD-sliced structure were analysed
+  SpmvKnobs knobs;
   uint32_t* first_owned = nullptr;  // [ntiles + 1]: first row whose start lies in tile t (rows for t = ntiles)
   void* carry = nullptr;            // T[ntiles]
   uint64_t ntiles = 0;
@@ -64,7 +83,7 @@ struct SpmvPlan {
   void* xh = nullptr;               // T[hot_k], rebuilt from x by every SpMV
   // XCD-sliced mode (analysis + one timing comparison on the first SpMV)
   SlicedPlan* sliced = nullptr;     // non-null: SpMV runs sliced
-  int64_t sliced_key = -1;          // configuration the decision was taken for (-1: not decided, 0: off)
+  float ms_plain = 0, ms_sliced = 0;  // the timed comparison of spam_spmv_prepare (0: not run)
 };
 
 void spmv_plan_free(SpmvPlan* p) {
@@ -525,6 +544,11 @@ __global__ void fill_zero_kernel(T* __restrict__ y, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = T(0);
 }
+template <class T>
+__global__ void fill_const_kernel(T* __restrict__ y, uint64_t n, T v) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = v;
+}
 
 // ---- hot-column analysis (once per matrix) ----------------------------------------------------------
 __global__ void col_count_kernel(const uint32_t* __restrict__ col, uint64_t nnz, uint32_t* __restrict__ cnt) {
@@ -648,6 +672,25 @@ static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
 }
+static SpmvKnobs read_knobs() {
+  SpmvKnobs k;
+  k.npt = env_int("SPAM_SPMV_NPT", 16) == 8 ? 8 : 16;
+  k.nt = env_int("SPAM_SPMV_NT", 1);
+  k.hot = env_int("SPAM_SPMV_HOT", 2);
+  k.hot_kb = k.hot ? env_int("SPAM_SPMV_HOT_KB", 3072) : 0;
+  k.sliced = env_int("SPAM_SPMV_SLICED", 1);
+  k.slice_kb = env_int("SPAM_SPMV_SLICE_KB", 3072);
+  k.lds_kb = env_int("SPAM_SPMV_LDS_KB", -1);
+  k.l0_kb = env_int("SPAM_SPMV_L0_KB", 16);
+  k.long_min = env_int("SPAM_SPMV_LONG", 0);
+  const int t = env_int("SPAM_SPMV_SLICED_TPB", 256), n = env_int("SPAM_SPMV_SLICED_NPT", 8);
+  k.tpb = t == 1024 ? 1024 : (t == 512 ? 512 : 256);
+  k.snpt = k.tpb == 1024 ? 4 : (k.tpb == 512 ? 8 : (n == 16 ? 16 : 8));
+  k.wgs = env_int("SPAM_SPMV_SLICED_WGS", 16);
+  k.pipe = env_int("SPAM_SPMV_PIPE", 1);
+  k.prof = env_int("SPAM_SPMV_PROF", 0);
+  return k;
+}
 
 // Smallest threshold t whose column set {cnt >= t} has at most kmax members; n = their number, mass = their total count.
 static int bisect_threshold(const uint32_t* cnt, uint32_t cols, uint64_t kmax, hipStream_t s, uint32_t* t_out,
@@ -725,12 +768,19 @@ struct SlicedPlan {
   void* descs = nullptr;          // SlabDesc<T>[NPART] on the device
   uint32_t* heads = nullptr;      // tile queue heads, HEAD_STRIDE words apart
   spam_csr* residual = nullptr;   // the non-empty short rows, compacted (row_ptr32 has ns + 1 entries)
+  // kept for spam_csr_values_changed (re-gather the values into sval / the residual without a new analysis)
+  uint32_t* code = nullptr;       // u32[cols]: table slot of a table column, the column itself otherwise
+  uint8_t* slab = nullptr;        // u8[cols]: part of a column (NSLAB = cold)
+  uint32_t* res32 = nullptr;      // u32[rows + 1]: entry offsets of the short rows inside the residual
+  uint64_t* sbase_d = nullptr;    // u64[NPART]: first entry of every part inside scol / sval
+  int hot = 2, prof = 0, wgs = 16;  // knobs the launches need
   float ms_plain = 0, ms_sliced = 0;
 };
 
 static void sliced_plan_free(SlicedPlan* q) {
   if (!q) return;
-  void* ptrs[] = {q->dest, q->xh, q->long_rows, q->short_rows, q->srow_ptr, q->scol, q->sval, q->sfo, q->scarry, q->partial, q->descs, q->heads};
+  void* ptrs[] = {q->dest, q->xh, q->long_rows, q->short_rows, q->srow_ptr, q->scol, q->sval, q->sfo, q->scarry, q->partial, q->descs, q->heads,
+                  q->code, q->slab, q->res32, q->sbase_d};
   for (void* p : ptrs)
     if (p) dev_free(p);
   if (q->residual) {
@@ -1052,7 +1102,8 @@ __global__ void sliced_count_kernel(const uint32_t* __restrict__ row_ptr, const 
   if (lane < NPART) cnt8[(uint64_t)lane * nl + w] = n;
 }
 // One wavefront per long row: move its entries into the slab arrays, storage order kept inside every (row, slab).
-template <class T>
+// VALS_ONLY: re-gather the values only (spam_csr_values_changed; the structure has not changed).
+template <class T, bool VALS_ONLY = false>
 __global__ void sliced_fill_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                    const T* __restrict__ val, const uint32_t* __restrict__ code,
                                    const uint8_t* __restrict__ slab, const uint32_t* __restrict__ long_rows, uint32_t nl,
@@ -1084,22 +1135,23 @@ __global__ void sliced_fill_kernel(const uint32_t* __restrict__ row_ptr, const u
       if (lane == kk) mybase += (uint64_t)__popcll(m);
     }
     if (act) {
-      scol[dst] = code[c];
+      if (!VALS_ONLY) scol[dst] = code[c];
       sval[dst] = v;
     }
   }
 }
-template <class T>
+template <class T, bool VALS_ONLY = false>
 __global__ void sliced_residual_fill_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-                                            const T* __restrict__ val, const uint32_t* __restrict__ is_long,
+                                            const T* __restrict__ val, uint32_t long_min,
                                             const uint32_t* __restrict__ res_ptr, uint32_t rows,
                                             uint32_t* __restrict__ out_col, T* __restrict__ out_val) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows || is_long[r]) return;
+  if (r >= rows) return;
   const uint32_t s = row_ptr[r], e = row_ptr[r + 1];
+  if (e - s >= long_min) return;  // a long row: lives in the slabs
   uint32_t o = res_ptr[r];
   for (uint32_t p = s; p < e; ++p, ++o) {
-    out_col[o] = col[p];
+    if (!VALS_ONLY) out_col[o] = col[p];
     out_val[o] = val[p];
   }
 }
@@ -1111,7 +1163,7 @@ __global__ void zero_u32_kernel(uint32_t* __restrict__ p, uint64_t n) {
 template <class T, int TPB, int NPT, bool LDS>
 static int sliced_launch_variant(const SlicedPlan* q, const T* x, hipStream_t s, unsigned* grid_out) {
   const size_t dyn = LDS ? (size_t)q->L * sizeof(T) : 0;  // LDS <=> q->use_lds
-  const int prof = grid_out ? 0 : env_int("SPAM_SPMV_PROF", 0);  // 1: in-kernel phase timers, 2: no phase 2 (experiment)
+  const int prof = grid_out ? 0 : q->prof;  // 1: in-kernel phase timers, 2: no phase 2 (experiment)
   auto kern = q->pipelined ? (prof == 2 ? spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 2>
                                         : (prof == 1 ? spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 1>
                                                      : spmv_sliced_pipe_kernel<T, TPB, NPT, LDS, 0>))
@@ -1136,7 +1188,7 @@ static int sliced_launch_variant(const SlicedPlan* q, const T* x, hipStream_t s,
     SPAM_HIP_TRY(hipGetDevice(&dev));
     SPAM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (per_cu < 1) return set_error(SPAM_E_HIP, "sliced SpMV kernel does not fit a CU (%zu B of LDS table)", dyn);
-    const int cap = env_int("SPAM_SPMV_SLICED_WGS", 16);
+    const int cap = q->wgs;
     if (per_cu > cap) per_cu = cap;
     uint64_t g = (uint64_t)per_cu * (uint64_t)cus;
     if (g > q->total_tiles) g = q->total_tiles;
@@ -1152,7 +1204,7 @@ static int sliced_launch_variant(const SlicedPlan* q, const T* x, hipStream_t s,
 template <class T>
 static int sliced_dispatch(const SlicedPlan* q, const T* x, hipStream_t s, unsigned* grid_out) {
   if (!grid_out && q->tpb == 256 && q->npt == 16 && !q->use_lds && !q->pipelined) {
-    const int prof = env_int("SPAM_SPMV_PROF", 0);
+    const int prof = q->prof;
     if (prof == 2) {  // experiment: phase 1 only (wrong results)
       spmv_sliced_kernel<T, 256, 16, false, 2><<<q->grid, 256, 0, s>>>((const SlabDesc<T>*)q->descs, x, q->L, q->heads);
       SPAM_CHECK_LAUNCH();
@@ -1183,19 +1235,16 @@ static int sliced_dispatch(const SlicedPlan* q, const T* x, hipStream_t s, unsig
   return set_error(SPAM_E_INVALID, "no sliced SpMV kernel for %d threads x %d entries", q->tpb, q->npt);
 }
 
-template <class T, class OffT>
-static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, hipStream_t s, bool allow_sliced);
-
 // Build the sliced structure.  Returns SPAM_OK with *out = nullptr when the matrix does not qualify.
 template <class T>
-static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPlan** out) {
+static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hipStream_t s, SlicedPlan** out) {
   *out = nullptr;
-  const int slice_kb = env_int("SPAM_SPMV_SLICE_KB", 3072);   // table bytes per XCD (of its 4 MB L2)
+  const int slice_kb = kn.slice_kb;   // table bytes per XCD (of its 4 MB L2)
   // the hottest slots of every slab are laid out contiguously (they stay in the CU's L1) and, when they cover enough
   // of the gathers to pay for the lost occupancy, copied to LDS by every workgroup.  SPAM_SPMV_LDS_KB: -1 decide
   // (16 KB if that level covers >= 15 % of the entries), 0 never, > 0 that many KB.
-  const int lds_cfg = env_int("SPAM_SPMV_LDS_KB", -1);
-  const int l0_kb = lds_cfg > 0 ? lds_cfg : env_int("SPAM_SPMV_L0_KB", 16);
+  const int lds_cfg = kn.lds_kb;
+  const int l0_kb = lds_cfg > 0 ? lds_cfg : kn.l0_kb;
   const uint64_t smax = (uint64_t)slice_kb * 1024 / sizeof(T);
   uint64_t lmax = (uint64_t)(l0_kb > 0 ? l0_kb : 0) * 1024 / sizeof(T);
   if (lmax > smax) lmax = smax;
@@ -1203,7 +1252,7 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
   if (a->cols + NSLAB * (smax + 32) >= 0xFFFFFFFFull) return SPAM_OK;
   if (!force && (a->cols * sizeof(T) <= (4u << 20) || a->nnz < (1u << 20))) return SPAM_OK;  // x fits one L2 / too small
   const uint32_t cols = (uint32_t)a->cols, rows = (uint32_t)a->rows;
-  const unsigned gc = (unsigned)((cols + 255) / 256), gr = (unsigned)((rows + 255) / 256);
+  const unsigned gc = (unsigned)(((uint64_t)cols + 255) / 256), gr = (unsigned)(((uint64_t)rows + 255) / 256);
 
   // -- columns: histogram, level thresholds --------------------------------------------------------------
   DevBuf cnt;
@@ -1233,13 +1282,9 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
     ~Guard() { if (q) sliced_plan_free(q); }
   } guard{q};
   q->use_lds = L > 0 && (lds_cfg > 0 || (lds_cfg < 0 && (double)m_lds >= 0.15 * (double)a->nnz));
-  q->pipelined = env_int("SPAM_SPMV_PIPE", 1) != 0;
+  q->pipelined = kn.pipe != 0;
   q->S = S, q->L = L, q->cover_table = cover_tab, q->cover_single = cover_single, q->n_table_cols = n_tab;
-  {
-    const int t = env_int("SPAM_SPMV_SLICED_TPB", 256), n = env_int("SPAM_SPMV_SLICED_NPT", 8);
-    q->tpb = t == 1024 ? 1024 : (t == 512 ? 512 : 256);
-    q->npt = q->tpb == 1024 ? 4 : (q->tpb == 512 ? 8 : (n == 16 ? 16 : 8));
-  }
+  q->tpb = kn.tpb, q->npt = kn.snpt, q->hot = kn.hot, q->prof = kn.prof, q->wgs = kn.wgs;
   const uint32_t tile = (uint32_t)(q->tpb * q->npt);
   {
     // rows worth 8 partials: a long row costs ~160 B of partial/row_ptr traffic, a short-path entry that misses
@@ -1247,8 +1292,7 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
     const double miss = std::max(0.05, 1.0 - cover_single);
     int lm = (int)std::ceil(1.8 / miss);
     lm = std::min(64, std::max(2, lm));
-    q->long_min = (uint32_t)env_int("SPAM_SPMV_LONG", lm);
-    if (q->long_min < 1) q->long_min = 1;
+    q->long_min = (uint32_t)(kn.long_min > 0 ? kn.long_min : lm);
   }
 
   DevBuf f0, f1, p0, p1, tmp, code, slab, dest;
@@ -1372,7 +1416,7 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
     SPAM_TRY(rv.alloc((nnz_res + 4) * sizeof(T)));
     SPAM_TRY(rp.alloc(((uint64_t)q->ns + 1) * 4));
     SPAM_TRY(short_rows.alloc(((uint64_t)q->ns + 1) * 4));
-    sliced_residual_fill_kernel<T><<<gr, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, is_long.as<uint32_t>(),
+    sliced_residual_fill_kernel<T><<<gr, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->long_min,
                                                       res32.as<uint32_t>(), rows, rc.as<uint32_t>(), rv.as<T>());
     SPAM_CHECK_LAUNCH();
     sliced_short_list_kernel<<<(unsigned)(((uint64_t)rows + 1 + 255) / 256), 256, 0, s>>>(
@@ -1396,34 +1440,45 @@ static int sliced_analyse(const spam_csr* a, int force, hipStream_t s, SlicedPla
   q->partial = partial.release();
   q->descs = descs.release();
   q->heads = (uint32_t*)heads.release();
+  q->code = (uint32_t*)code.release();
+  q->slab = (uint8_t*)slab.release();
+  q->res32 = (uint32_t*)res32.release();
+  q->sbase_d = (uint64_t*)sbase_d.release();
   SPAM_TRY(sliced_dispatch<T>(q, nullptr, s, &q->grid));
+  // the short rows' own hot-column table (analysed on the residual's histogram)
+  res->spmv_plan = new (std::nothrow) SpmvPlan();  // only the hot-column part is used
+  if (!res->spmv_plan) return set_error(SPAM_E_OOM, "host allocation failed");
+  SPAM_TRY(spmv_hot_analyse<T>(res, res->spmv_plan, kn.hot_kb, s));
   guard.q = nullptr;
   *out = q;
   return SPAM_OK;
 }
 
-// Short rows: their own hot-column table (analysed on the residual's histogram), one lane per row.
+// spam_csr_values_changed for the sliced structure: gather the matrix's current values again (same traversal as the
+// analysis, values only).
+template <class T>
+static int sliced_refresh_values(const spam_csr* a, SlicedPlan* q, hipStream_t s) {
+  const uint32_t rows = (uint32_t)a->rows;
+  const unsigned gw = (unsigned)(((uint64_t)q->nl * 64 + 255) / 256), gr = (unsigned)(((uint64_t)rows + 255) / 256);
+  if (q->nl) {
+    sliced_fill_kernel<T, true><<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->code, q->slab, q->long_rows,
+                                                   q->nl, q->srow_ptr, q->sbase_d, q->scol, (T*)q->sval);
+    SPAM_CHECK_LAUNCH();
+  }
+  sliced_residual_fill_kernel<T, true><<<gr, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->long_min, q->res32, rows,
+                                                          q->residual->col_idx, (T*)q->residual->vals);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
+}
+
+// Short rows: one lane per row, with the hot-column table the analysis built on the residual's histogram.
 template <class T>
 static int residual_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, hipStream_t s) {
-  spam_csr* res = q->residual;
-  if (!res->spmv_plan) {
-    res->spmv_plan = new (std::nothrow) SpmvPlan();  // only the hot-column part is used
-    if (!res->spmv_plan) return set_error(SPAM_E_OOM, "host allocation failed");
-  }
-  SpmvPlan* pm = res->spmv_plan;
-  const int hot_cfg = env_int("SPAM_SPMV_HOT", 2);
-  const int hot_kb = hot_cfg ? env_int("SPAM_SPMV_HOT_KB", 3072) : 0;
-  if (pm->hot_kb != hot_kb) {
-    if (pm->ja_hot) dev_free(pm->ja_hot);
-    if (pm->hot_cols) dev_free(pm->hot_cols);
-    if (pm->xh) dev_free(pm->xh);
-    pm->ja_hot = pm->hot_cols = nullptr;
-    pm->xh = nullptr;
-    SPAM_TRY(spmv_hot_analyse<T>(res, pm, hot_kb, s));
-  }
+  const spam_csr* res = q->residual;
+  const SpmvPlan* pm = res->spmv_plan;
   if (q->ns == 0) return SPAM_OK;
   const unsigned g = (q->ns + 255) / 256;
-  if (pm->hot_k) {
+  if (pm && pm->hot_k && q->hot) {
     xh_build_kernel<T><<<(pm->hot_k + 255) / 256, 256, 0, s>>>(x, pm->hot_cols, pm->hot_k, (T*)pm->xh);
     SPAM_CHECK_LAUNCH();
     spmv_short_rows_kernel<T, 2><<<g, 256, 0, s>>>(res->row_ptr32, pm->ja_hot, (const T*)res->vals, x, (const T*)pm->xh,
@@ -1458,20 +1513,9 @@ static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, 
 // ---- the plain path ---------------------------------------------------------------------------------------
 template <class T, class OffT>
 static int plain_run(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, hipStream_t s) {
-  const int nt_cfg = env_int("SPAM_SPMV_NT", 1);  // non-temporal ja/a stream: keeps L2 for x (+4..6 % on random gathers)
-  const int hot_cfg = env_int("SPAM_SPMV_HOT", 2);        // 0 off, 1 per-lane base select, 2 cold gathers non-temporal
-  const int hot_kb = hot_cfg ? env_int("SPAM_SPMV_HOT_KB", 3072) : 0;  // of the 4 MB L2 per XCD
-  spam_csr* am = const_cast<spam_csr*>(a);
-  if (am->spmv_plan->hot_kb != hot_kb) {
-    SpmvPlan* pm = am->spmv_plan;
-    if (pm->ja_hot) dev_free(pm->ja_hot);
-    if (pm->hot_cols) dev_free(pm->hot_cols);
-    if (pm->xh) dev_free(pm->xh);
-    pm->ja_hot = pm->hot_cols = nullptr;
-    pm->xh = nullptr;
-    SPAM_TRY(spmv_hot_analyse<T>(a, pm, hot_kb, s));
-  }
   const SpmvPlan* p = a->spmv_plan;
+  const int nt_cfg = p->knobs.nt;     // non-temporal ja/a stream: keeps L2 for x (+4..6 % on random gathers)
+  const int hot_cfg = p->knobs.hot;   // 0 off, 1 per-lane base select, 2 cold gathers non-temporal
   const int npt = p->npt;
   const uint32_t tile = SPMV_TPB * npt;
   const unsigned grid = (unsigned)p->ntiles;
@@ -1529,83 +1573,137 @@ static int time_runs(F&& run, hipStream_t s, float* ms_out) {
   return rc;
 }
 
+// The row -> tile map of the plain path: depends on row_ptr only, one small kernel, no host synchronisation.
+// Caller holds the plan's lock (or is the only user of the handle).
+template <class OffT>
+static int build_tile_map(const spam_csr* a, const OffT* row_ptr, SpmvPlan* p, size_t vsize, hipStream_t s) {
+  const uint32_t tile = SPMV_TPB * p->knobs.npt;
+  p->npt = p->knobs.npt;
+  p->ntiles = (a->nnz + tile - 1) / tile;
+  if (a->nnz == 0) return SPAM_OK;
+  DevBuf fo, ca;
+  SPAM_TRY(fo.alloc((p->ntiles + 1) * 4));
+  SPAM_TRY(ca.alloc(p->ntiles * vsize));
+  spmv_first_owned_kernel<OffT><<<(unsigned)((p->ntiles + 1 + 255) / 256), 256, 0, s>>>(row_ptr, (uint32_t)a->rows, tile,
+                                                                                       p->ntiles, (uint32_t*)fo.p);
+  SPAM_CHECK_LAUNCH();
+  p->first_owned = (uint32_t*)fo.release();
+  p->carry = ca.release();
+  return SPAM_OK;
+}
+
+// First use of a handle that was never prepared: the plain tile path without any analysis (no hot-column table, no
+// XCD-sliced structure) — asynchronous apart from two small allocations.  spam_spmv_prepare upgrades the plan.
 template <class T, class OffT>
-static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, hipStream_t s, bool allow_sliced) {
+static int ensure_plan(const spam_csr* a, const OffT* row_ptr, hipStream_t s) {
+  spam_csr* am = const_cast<spam_csr*>(a);
+  std::lock_guard<std::mutex> lk(am->plan_mu);
+  if (am->spmv_plan) return SPAM_OK;
+  SpmvPlan* p = new (std::nothrow) SpmvPlan();
+  if (!p) return set_error(SPAM_E_OOM, "host allocation failed");
+  p->knobs = read_knobs();
+  p->hot_kb = 0;
+  if (int e = build_tile_map<OffT>(a, row_ptr, p, sizeof(T), s)) {
+    spmv_plan_free(p);
+    return e;
+  }
+  __atomic_store_n(&am->spmv_plan, p, __ATOMIC_RELEASE);
+  return SPAM_OK;
+}
+
+template <class T, class OffT>
+static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, hipStream_t s) {
   if (a->nnz == 0) {
     fill_zero_kernel<T><<<(unsigned)((a->rows + 255) / 256), 256, 0, s>>>(y, a->rows);
     SPAM_CHECK_LAUNCH();
     return SPAM_OK;
   }
-  const int npt_cfg = env_int("SPAM_SPMV_NPT", 16);  // read per call so one process can A/B variants
-  const int npt = (npt_cfg == 8) ? 8 : 16;
-  const uint32_t tile = SPMV_TPB * npt;
-  spam_csr* am = const_cast<spam_csr*>(a);
-  if (!am->spmv_plan || am->spmv_plan->npt != npt) {
-    if (am->spmv_plan) spmv_plan_free(am->spmv_plan);
-    am->spmv_plan = nullptr;
-    SpmvPlan* p = new (std::nothrow) SpmvPlan();
-    if (!p) return set_error(SPAM_E_OOM, "host allocation failed");
-    p->npt = npt;
-    p->ntiles = (a->nnz + tile - 1) / tile;
-    DevBuf fo, ca;
-    if (int e = fo.alloc((p->ntiles + 1) * 4)) {
-      delete p;
-      return e;
-    }
-    if (int e = ca.alloc(p->ntiles * sizeof(T))) {
-      delete p;
-      return e;
-    }
-    p->first_owned = (uint32_t*)fo.release();
-    p->carry = ca.release();
-    spmv_first_owned_kernel<OffT><<<(unsigned)((p->ntiles + 1 + 255) / 256), 256, 0, s>>>(
-        row_ptr, (uint32_t)a->rows, tile, p->ntiles, p->first_owned);
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) {
-      spmv_plan_free(p);
-      return set_error(SPAM_E_HIP, "spmv_first_owned_kernel: %s", hipGetErrorString(le));
-    }
-    am->spmv_plan = p;
-  }
-  SpmvPlan* pm = am->spmv_plan;
-  // XCD-sliced mode: 0 never, 1 let the analysis decide and then time both paths once on this x, 2 always (tests)
-  const int sl_cfg = allow_sliced ? env_int("SPAM_SPMV_SLICED", 1) : 0;
-  int64_t sl_key = 0;
-  if (sl_cfg) {
-    const char* knobs[] = {"SPAM_SPMV_SLICE_KB", "SPAM_SPMV_LDS_KB", "SPAM_SPMV_L0_KB", "SPAM_SPMV_LONG", "SPAM_SPMV_SLICED_TPB", "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS", "SPAM_SPMV_PIPE"};
-    uint64_t h = 1469598103934665603ull + (uint64_t)sl_cfg;
-    for (const char* k : knobs) h = (h ^ (uint64_t)(uint32_t)env_int(k, -1)) * 1099511628211ull;
-    sl_key = (int64_t)(h >> 1) + 1;  // never 0 or -1
-  }
-  if (pm->sliced_key != sl_key) {
-    if (pm->sliced) sliced_plan_free(pm->sliced);
-    pm->sliced = nullptr;
-    pm->sliced_key = sl_key;
-    if (sl_cfg) {
-      SlicedPlan* q = nullptr;
-      SPAM_TRY(sliced_analyse<T>(a, sl_cfg == 2, s, &q));
-      if (q && sl_cfg == 1) {  // keep it only if it is faster on this matrix
-        SPAM_TRY(time_runs([&] { return plain_run<T, OffT>(a, row_ptr, x, y, s); }, s, &q->ms_plain));
-        SPAM_TRY(time_runs([&] { return sliced_run<T>(a, q, x, y, s); }, s, &q->ms_sliced));
-        if (!(q->ms_sliced < q->ms_plain)) {
-          sliced_plan_free(q);
-          q = nullptr;
-        }
-      }
-      pm->sliced = q;
-    }
-  }
+  if (!__atomic_load_n(&a->spmv_plan, __ATOMIC_ACQUIRE)) SPAM_TRY((ensure_plan<T, OffT>(a, row_ptr, s)));
+  const SpmvPlan* pm = a->spmv_plan;
   if (pm->sliced) return sliced_run<T>(a, pm->sliced, x, y, s);
   return plain_run<T, OffT>(a, row_ptr, x, y, s);
 }
 
+// spam_spmv_prepare: the analysis step of CSR-adaptive, done once per matrix and never inside spam_spmv_dev.
+//   * environment knobs are read here, once;
+//   * hot-column table of the plain path (column histogram + threshold bisection: host-synchronised);
+//   * the XCD-sliced structure where the matrix qualifies (SPAM_SPMV_SLICED = 1: kept only if three timed runs on `x`
+//     beat the plain path by more than 3 %; 2: always; 0: never).  x = NULL times on a vector of ones.
+// The choice fixes the summation order of every later SpMV on this handle (results are deterministic per plan).
+template <class T, class OffT>
+static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(a->plan_mu);
+  if (a->spmv_plan) {
+    SpmvPlan* old = a->spmv_plan;
+    a->spmv_plan = nullptr;
+    SPAM_HIP_TRY(hipStreamSynchronize(s));  // SpMVs queued on the old plan
+    spmv_plan_free(old);
+  }
+  if (a->nnz == 0) return SPAM_OK;
+  SpmvPlan* p = new (std::nothrow) SpmvPlan();
+  if (!p) return set_error(SPAM_E_OOM, "host allocation failed");
+  struct Guard {
+    SpmvPlan* p;
+    ~Guard() { if (p) spmv_plan_free(p); }
+  } guard{p};
+  p->knobs = read_knobs();
+  SPAM_TRY(build_tile_map<OffT>(a, row_ptr, p, sizeof(T), s));
+  SPAM_TRY(spmv_hot_analyse<T>(a, p, p->knobs.hot_kb, s));
+  const int sl_cfg = p->knobs.sliced;
+  if (sl_cfg) {
+    SlicedPlan* q = nullptr;
+    SPAM_TRY(sliced_analyse<T>(a, p->knobs, sl_cfg == 2, s, &q));
+    if (q && sl_cfg == 1) {  // keep it only if it is faster on this matrix
+      struct QGuard {
+        SlicedPlan* q;
+        ~QGuard() { if (q) sliced_plan_free(q); }
+      } qg{q};
+      DevBuf xs, ys;
+      SPAM_TRY(ys.alloc(a->rows * sizeof(T)));
+      const T* xt = x;
+      if (!xt) {
+        SPAM_TRY(xs.alloc(a->cols * sizeof(T)));
+        fill_const_kernel<T><<<(unsigned)((a->cols + 255) / 256), 256, 0, s>>>((T*)xs.p, a->cols, T(1));
+        SPAM_CHECK_LAUNCH();
+        xt = (const T*)xs.p;
+      }
+      a->spmv_plan = p;  // plain_run reads the plan through the handle
+      int rc = time_runs([&] { return plain_run<T, OffT>(a, row_ptr, xt, (T*)ys.p, s); }, s, &q->ms_plain);
+      if (rc == SPAM_OK) rc = time_runs([&] { return sliced_run<T>(a, q, xt, (T*)ys.p, s); }, s, &q->ms_sliced);
+      a->spmv_plan = nullptr;
+      SPAM_TRY(rc);
+      SPAM_HIP_TRY(hipStreamSynchronize(s));
+      p->ms_plain = q->ms_plain, p->ms_sliced = q->ms_sliced;
+      if (q->ms_sliced < 0.97f * q->ms_plain) {
+        qg.q = nullptr;
+      } else {
+        q = nullptr;  // (freed by the guard)
+      }
+    }
+    p->sliced = q;
+  }
+  p->prepared = true;
+  guard.p = nullptr;
+  __atomic_store_n(&a->spmv_plan, p, __ATOMIC_RELEASE);
+  return SPAM_OK;
+}
+
 int spmv_launch(const spam_csr* a, const void* d_x, void* d_y, hipStream_t s) {
   if (a->dtype == SPAM_F64) {
-    if (a->row_ptr32) return spmv_typed<double, uint32_t>(a, a->row_ptr32, (const double*)d_x, (double*)d_y, s, true);
-    return spmv_typed<double, uint64_t>(a, a->row_ptr, (const double*)d_x, (double*)d_y, s, true);
+    if (a->row_ptr32) return spmv_typed<double, uint32_t>(a, a->row_ptr32, (const double*)d_x, (double*)d_y, s);
+    return spmv_typed<double, uint64_t>(a, a->row_ptr, (const double*)d_x, (double*)d_y, s);
   }
-  if (a->row_ptr32) return spmv_typed<float, uint32_t>(a, a->row_ptr32, (const float*)d_x, (float*)d_y, s, true);
-  return spmv_typed<float, uint64_t>(a, a->row_ptr, (const float*)d_x, (float*)d_y, s, true);
+  if (a->row_ptr32) return spmv_typed<float, uint32_t>(a, a->row_ptr32, (const float*)d_x, (float*)d_y, s);
+  return spmv_typed<float, uint64_t>(a, a->row_ptr, (const float*)d_x, (float*)d_y, s);
+}
+
+static int spmv_prepare(spam_csr* a, const void* d_x, hipStream_t s) {
+  if (a->dtype == SPAM_F64) {
+    if (a->row_ptr32) return prepare_typed<double, uint32_t>(a, a->row_ptr32, (const double*)d_x, s);
+    return prepare_typed<double, uint64_t>(a, a->row_ptr, (const double*)d_x, s);
+  }
+  if (a->row_ptr32) return prepare_typed<float, uint32_t>(a, a->row_ptr32, (const float*)d_x, s);
+  return prepare_typed<float, uint64_t>(a, a->row_ptr, (const float*)d_x, s);
 }
 
 template <class T>
@@ -1659,8 +1757,8 @@ int spam_spmv_sliced_info(const spam_csr* a, int* active, uint64_t* long_rows, u
   if (lds_slots) *lds_slots = q ? q->L : 0;  // contiguous hottest slots (L1-resident; in LDS with SPAM_SPMV_LDS_KB)
   if (cover_table) *cover_table = q ? q->cover_table : 0.0;
   if (cover_single) *cover_single = q ? q->cover_single : 0.0;
-  if (ms_plain) *ms_plain = q ? q->ms_plain : 0.0;
-  if (ms_sliced) *ms_sliced = q ? q->ms_sliced : 0.0;
+  if (ms_plain) *ms_plain = a->spmv_plan ? a->spmv_plan->ms_plain : 0.0;
+  if (ms_sliced) *ms_sliced = a->spmv_plan ? a->spmv_plan->ms_sliced : 0.0;
   return SPAM_OK;
 }
 
@@ -1668,6 +1766,22 @@ int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y) {
   clear_error();
   if (!a || !d_x || !d_y) return set_error(SPAM_E_INVALID, "NULL argument");
   return spmv_launch(a, d_x, d_y, stream());
+}
+
+int spam_spmv_prepare(spam_csr* a, const void* d_x) {
+  clear_error();
+  if (!a) return set_error(SPAM_E_INVALID, "matrix is NULL");
+  return spmv_prepare(a, d_x, stream());
+}
+
+int spam_csr_values_changed(spam_csr* a) {
+  clear_error();
+  if (!a) return set_error(SPAM_E_INVALID, "matrix is NULL");
+  std::lock_guard<std::mutex> lk(a->plan_mu);
+  SpmvPlan* p = a->spmv_plan;
+  if (!p || !p->sliced) return SPAM_OK;  // the plain path reads the values where they are
+  if (a->dtype == SPAM_F64) return sliced_refresh_values<double>(a, p->sliced, stream());
+  return sliced_refresh_values<float>(a, p->sliced, stream());
 }
 
 }  // extern "C"

@@ -35,7 +35,8 @@ def main():
                 del os.environ[k]
             for k, val in v.items():
                 os.environ[k] = str(val)
-            dA.spmv_dev(x.data_ptr(), y.data_ptr())  # (re)build plan + warm
+            dA.spmv_prepare(x.data_ptr())  # (re)build the plan with these knobs
+            dA.spmv_dev(x.data_ptr(), y.data_ptr())
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
