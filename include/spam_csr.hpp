@@ -28,8 +28,8 @@ inline void check(int status) {
 
 template <class T, bool IS_SORTED>
 class CsrMatrix {
-  static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value,
-                "the HIP back end serves f32 / f64; other T keep the reference's CPU path");
+  static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value || std::is_same<T, int64_t>::value,
+                "the HIP back end serves f32 / f64 / Wrapping<i64>; other T keep the reference's CPU path");
 
  public:
   // CsrMatrix { rows, cols, vals, indices, offsets }  (lib.rs:26-32)
@@ -94,6 +94,8 @@ class CsrMatrix {
     int st;
     if constexpr (std::is_same<T, double>::value)
       st = spam_spgemm_numeric_f64(plan, B2 ? 1 : 0, offsets.data(), indices.data(), vals.data());
+    else if constexpr (std::is_same<T, int64_t>::value)
+      st = spam_spgemm_numeric_i64(plan, B2 ? 1 : 0, offsets.data(), indices.data(), vals.data());
     else
       st = spam_spgemm_numeric_f32(plan, B2 ? 1 : 0, offsets.data(), indices.data(), vals.data());
     spam_spgemm_plan_free(plan);
@@ -118,6 +120,8 @@ class CsrMatrix {
     std::vector<T> y(rows_);
     if constexpr (std::is_same<T, double>::value)
       check(spam_spmv_f64(device(), x.data(), y.data()));
+    else if constexpr (std::is_same<T, int64_t>::value)
+      check(spam_spmv_i64(device(), x.data(), y.data()));
     else
       check(spam_spmv_f32(device(), x.data(), y.data()));
     return y;
@@ -128,6 +132,9 @@ class CsrMatrix {
     if (!dev_) {
       if constexpr (std::is_same<T, double>::value)
         check(spam_csr_upload_f64(rows_, cols_, indices_.size(), offsets_.data(), indices_.data(), vals_.data(),
+                                  IS_SORTED, &dev_));
+      else if constexpr (std::is_same<T, int64_t>::value)
+        check(spam_csr_upload_i64(rows_, cols_, indices_.size(), offsets_.data(), indices_.data(), vals_.data(),
                                   IS_SORTED, &dev_));
       else
         check(spam_csr_upload_f32(rows_, cols_, indices_.size(), offsets_.data(), indices_.data(), vals_.data(),
@@ -147,6 +154,8 @@ class CsrMatrix {
     int st;
     if constexpr (std::is_same<T, double>::value)
       st = spam_csr_download_f64(c, offsets.data(), indices.data(), vals.data());
+    else if constexpr (std::is_same<T, int64_t>::value)
+      st = spam_csr_download_i64(c, offsets.data(), indices.data(), vals.data());
     else
       st = spam_csr_download_f32(c, offsets.data(), indices.data(), vals.data());
     spam_csr_free(c);

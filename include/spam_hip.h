@@ -40,10 +40,14 @@ extern "C" {
 #define SPAM_E_HIP 4         /* HIP runtime error (message has the hipError string) */
 #define SPAM_E_OVERFLOW 5    /* checked_add overflow (mul_hash.rs:47-48, lib.rs:270) */
 #define SPAM_E_UNSUPPORTED 6 /* valid request this build cannot serve (message says why) */
-#define SPAM_E_DTYPE 7       /* f32 entry point called on an f64 handle or vice versa */
+#define SPAM_E_DTYPE 7       /* entry point of one value type called on a handle of another */
 
 #define SPAM_F32 0
 #define SPAM_F64 1
+#define SPAM_I64 2 /* Wrapping<i64>: two's-complement wrap-around, the arithmetic of the reference's own hot-path test
+                    * (Wrapping<i8>, spam_csr/src/tests.rs:356-371) and of its MatrixType::Integer bench files (parsed
+                    * as i64, spam_csr/src/lib.rs:421-424).  Integer sums do not depend on the order of the additions, so
+                    * the GPU result equals the reference BIT FOR BIT in values as well as in structure. */
 
 typedef struct spam_csr spam_csr;                 /* device-resident CsrMatrix<T, IS_SORTED> */
 typedef struct spam_spgemm_plan spam_spgemm_plan; /* state between symbolic and numeric (mul_hash.rs:22,28) */
@@ -72,6 +76,10 @@ int spam_hip_synchronize(void);
 /* The library keeps freed device blocks for reuse (a 100 GB C costs seconds of hipMalloc otherwise);
  * this hands all cached blocks back to the driver. */
 int spam_hip_trim(void);
+/* Measurement aid: effective GB/s (bytes read + bytes written) of a float4 copy kernel over `bytes` bytes, `reps`
+ * launches — the streaming ceiling of this device, measured in the caller's process (bench.py prints it beside the
+ * roofline fractions; MI355X_MICROARCH.md quotes 6.29 TB/s). */
+int spam_hip_copy_gbps(uint64_t bytes, int reps, double* gbps_out);
 /* Message of the last failing call on this thread ("" if none).  Never NULL. */
 const char* spam_last_error(void);
 /* Library/ABI version: major*1000 + minor. */
@@ -86,6 +94,8 @@ int spam_csr_upload_f64(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64
                         const uint64_t* indices, const double* vals, int is_sorted, spam_csr** out);
 int spam_csr_upload_f32(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t* offsets,
                         const uint64_t* indices, const float* vals, int is_sorted, spam_csr** out);
+int spam_csr_upload_i64(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t* offsets,
+                        const uint64_t* indices, const int64_t* vals, int is_sorted, spam_csr** out);
 
 /* Wrap arrays already in HBM (no copy, caller keeps ownership and must outlive the handle):
  * d_row_ptr uint64[rows+1], d_col_idx uint32[nnz], d_vals T[nnz]; all 16-byte aligned. */
@@ -109,6 +119,7 @@ int spam_csr_device_ptrs(const spam_csr* m, const uint64_t** d_row_ptr, const ui
 /* Copy back into caller-allocated host Vecs (offsets[rows+1], indices[nnz] widened to usize, vals[nnz]). */
 int spam_csr_download_f64(const spam_csr* m, uint64_t* offsets, uint64_t* indices, double* vals);
 int spam_csr_download_f32(const spam_csr* m, uint64_t* offsets, uint64_t* indices, float* vals);
+int spam_csr_download_i64(const spam_csr* m, uint64_t* offsets, uint64_t* indices, int64_t* vals);
 /* Sort every row by column in place: CsrMatrix<T, false> -> CsrMatrix<T, true> (what `From<DokMatrix>` guarantees,
  * spam_csr/src/lib.rs:315-334).  Only for handles that own their arrays (uploads, SpGEMM results). */
 int spam_csr_sort_rows(spam_csr* m);
@@ -127,6 +138,7 @@ int spam_csr_add(const spam_csr* a, const spam_csr* b, int subtract, spam_csr** 
  * mul_hash.rs:145-163): rows without entries give 0.  x has cols(A) entries, y rows(A). */
 int spam_spmv_f64(const spam_csr* a, const double* x_host, double* y_host); /* host slices (&[T] -> Vec<T>) */
 int spam_spmv_f32(const spam_csr* a, const float* x_host, float* y_host);
+int spam_spmv_i64(const spam_csr* a, const int64_t* x_host, int64_t* y_host);
 int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y); /* device-resident vectors, asynchronous */
 /* The analysis step (CSR-adaptive's row binning; here: row -> tile map, hot-column table, XCD-sliced structure), done
  * ONCE per matrix and never inside spam_spmv_*: reads the SPAM_SPMV_* environment knobs, synchronises with the host,
@@ -175,6 +187,8 @@ int spam_spgemm_numeric_f64(spam_spgemm_plan* plan, int sort_rows, uint64_t* off
                             uint64_t* indices_out /* nnz */, double* vals_out /* nnz */);
 int spam_spgemm_numeric_f32(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out, uint64_t* indices_out,
                             float* vals_out);
+int spam_spgemm_numeric_i64(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out, uint64_t* indices_out,
+                            int64_t* vals_out);
 /* Same, but C stays in HBM as a new handle (free with spam_csr_free). */
 int spam_spgemm_numeric_dev(spam_spgemm_plan* plan, int sort_rows, spam_csr** c_out);
 int spam_spgemm_plan_stats(const spam_spgemm_plan* plan, spam_spgemm_stats* stats);
@@ -183,6 +197,18 @@ void spam_spgemm_plan_free(spam_spgemm_plan* plan);
 /* One call, device-resident: symbolic + allocate + numeric.  stats may be NULL. */
 int spam_spgemm_dev(const spam_csr* a, const spam_csr* b, int sort_rows, spam_csr** c_out,
                     spam_spgemm_stats* stats);
+
+/* One rank's share of the row-sharded product C = A B on `world` GPUs, in one call: rows_to_threads' partition
+ * (mul_hash.rs:38-64) with tnum = world on F_i + row_overhead * [F_i > 0] (computed on the device; every rank gets the
+ * same offsets), a zero-copy view of A's rows [*row_lo, *row_hi) and the two-phase SpGEMM of that block with all of B.
+ * a_full / b_full are this rank's complete copies of A and B (for C = A A the same handle; B arrives through the
+ * all-gather of the ranks' row shards, which is the HOST's step: exchange the three arrays of spam_csr_device_ptrs
+ * with RCCL — INTEGRATION.md shows the grouped ncclSend / ncclRecv sequence — and wrap the result with
+ * spam_csr_from_device).  *c_block = the block of C (NULL when the block has no rows); C stays row-sharded.
+ * row_overhead: 2300 measured on MI355X (spam_rows_to_parts_weighted). */
+int spam_spgemm_rank_step(const spam_csr* a_full, const spam_csr* b_full, uint64_t rank, uint64_t world,
+                          uint64_t row_overhead, int sort_rows, spam_csr** c_block, uint64_t* row_lo, uint64_t* row_hi,
+                          spam_spgemm_stats* stats);
 
 /* rows_to_threads (mul_hash.rs:38-64) with tnum = nparts: per-row intermediate-product counts and the
  * flop-balanced contiguous row ranges rows_offset[0..nparts].  row_flops_out may be NULL. */

@@ -12,9 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspam_hip.so")
 
 SPAM_OK = 0
-SPAM_F32, SPAM_F64 = 0, 1
+SPAM_F32, SPAM_F64, SPAM_I64 = 0, 1, 2
 ERR_NAMES = {1: "SPAM_E_INVALID", 2: "SPAM_E_INDEX_RANGE", 3: "SPAM_E_OOM", 4: "SPAM_E_HIP",
              5: "SPAM_E_OVERFLOW", 6: "SPAM_E_UNSUPPORTED", 7: "SPAM_E_DTYPE"}
+DTYPE_SUFFIX = {0: "f32", 1: "f64", 2: "i64"}
 
 
 class SpamError(RuntimeError):
@@ -53,10 +54,12 @@ SYMBOLS = {
     "spam_hip_set_stream": (C.c_int, [_P]),
     "spam_hip_synchronize": (C.c_int, []),
     "spam_hip_trim": (C.c_int, []),
+    "spam_hip_copy_gbps": (C.c_int, [_U64, C.c_int, C.POINTER(C.c_double)]),
     "spam_last_error": (C.c_char_p, []),
     "spam_version": (C.c_int, []),
     "spam_csr_upload_f64": (C.c_int, [_U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
     "spam_csr_upload_f32": (C.c_int, [_U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
+    "spam_csr_upload_i64": (C.c_int, [_U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
     "spam_csr_from_device": (C.c_int, [C.c_int, _U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
     "spam_csr_from_sorted_coo": (C.c_int, [C.c_int, _U64, _U64, _U64, _P, _P, _P, C.c_int, _PP]),
     "spam_csr_row_block": (C.c_int, [_P, _U64, _U64, _PP]),
@@ -65,12 +68,14 @@ SYMBOLS = {
     "spam_csr_device_ptrs": (C.c_int, [_P, _PP, _PP, _PP]),
     "spam_csr_download_f64": (C.c_int, [_P, _P, _P, _P]),
     "spam_csr_download_f32": (C.c_int, [_P, _P, _P, _P]),
+    "spam_csr_download_i64": (C.c_int, [_P, _P, _P, _P]),
     "spam_csr_sort_rows": (C.c_int, [_P]),
     "spam_csr_invariants": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "spam_csr_add": (C.c_int, [_P, _P, C.c_int, _PP]),
     "spam_csr_free": (None, [_P]),
     "spam_spmv_f64": (C.c_int, [_P, _P, _P]),
     "spam_spmv_f32": (C.c_int, [_P, _P, _P]),
+    "spam_spmv_i64": (C.c_int, [_P, _P, _P]),
     "spam_spmv_dev": (C.c_int, [_P, _P, _P]),
     "spam_spmv_prepare": (C.c_int, [_P, _P]),
     "spam_csr_values_changed": (C.c_int, [_P]),
@@ -79,10 +84,13 @@ SYMBOLS = {
     "spam_spgemm_symbolic": (C.c_int, [_P, _P, _PP, C.POINTER(_U64)]),
     "spam_spgemm_numeric_f64": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "spam_spgemm_numeric_f32": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "spam_spgemm_numeric_i64": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "spam_spgemm_numeric_dev": (C.c_int, [_P, C.c_int, _PP]),
     "spam_spgemm_plan_stats": (C.c_int, [_P, C.POINTER(SpgemmStats)]),
     "spam_spgemm_plan_free": (None, [_P]),
     "spam_spgemm_dev": (C.c_int, [_P, _P, C.c_int, _PP, C.POINTER(SpgemmStats)]),
+    "spam_spgemm_rank_step": (C.c_int, [_P, _P, _U64, _U64, _U64, C.c_int, _PP, C.POINTER(_U64), C.POINTER(_U64),
+                                        C.POINTER(SpgemmStats)]),
     "spam_rows_to_parts": (C.c_int, [_P, _P, _U64, _P, _P]),
     "spam_rows_to_parts_weighted": (C.c_int, [_P, _P, _U64, _U64, _P]),
 }

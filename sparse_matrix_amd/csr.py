@@ -13,10 +13,16 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import SPAM_F32, SPAM_F64, SpamError, SpgemmStats, check
+from ._lib import DTYPE_SUFFIX, SPAM_F32, SPAM_F64, SPAM_I64, SpamError, SpgemmStats, check
 
-_NP2DT = {np.dtype(np.float32): SPAM_F32, np.dtype(np.float64): SPAM_F64}
-_DT2NP = {SPAM_F32: np.float32, SPAM_F64: np.float64}
+# int64 = Wrapping<i64> (the reference's integer type: tests.rs:356-371 uses Wrapping<i8>, the bench parses i64)
+_NP2DT = {np.dtype(np.float32): SPAM_F32, np.dtype(np.float64): SPAM_F64, np.dtype(np.int64): SPAM_I64}
+_DT2NP = {SPAM_F32: np.float32, SPAM_F64: np.float64, SPAM_I64: np.int64}
+
+
+def _typed(name: str, dt: int):
+    """The entry point of a value type: spam_<name>_{f32,f64,i64}."""
+    return getattr(_lib.load(), f"spam_{name}_{DTYPE_SUFFIX[dt]}")
 
 
 def _vp(a):
@@ -39,13 +45,13 @@ class DeviceCsr:
         indices = np.ascontiguousarray(indices, dtype=np.uint64)
         vals = np.ascontiguousarray(vals)
         if vals.dtype not in _NP2DT:
-            raise TypeError(f"GPU path supports f32/f64 values, not {vals.dtype}")
+            raise TypeError(f"GPU path supports f32 / f64 / int64 values, not {vals.dtype}")
         if offsets.size != rows + 1:
             raise SpamError(1, "len(offsets) != rows + 1 (invariant 2)")
         if indices.size != vals.size:
             raise SpamError(1, "len(indices) != len(vals) (invariant 1)")
         h = C.c_void_p()
-        fn = L.spam_csr_upload_f64 if vals.dtype == np.float64 else L.spam_csr_upload_f32
+        fn = _typed("csr_upload", _NP2DT[vals.dtype])
         check(fn(rows, cols, vals.size, _vp(offsets), _vp(indices), _vp(vals), int(bool(is_sorted)), C.byref(h)))
         return cls(h)
 
@@ -64,7 +70,7 @@ class DeviceCsr:
         import torch
 
         assert row_ptr.dtype == torch.int64 and col_idx.dtype == torch.int32
-        dt = SPAM_F64 if vals.dtype == torch.float64 else SPAM_F32
+        dt = {torch.float64: SPAM_F64, torch.float32: SPAM_F32, torch.int64: SPAM_I64}[vals.dtype]
         return cls.from_device(dt, rows, cols, int(col_idx.numel()), row_ptr.data_ptr(), col_idx.data_ptr(),
                                vals.data_ptr(), is_sorted, keepalive=(row_ptr, col_idx, vals))
 
@@ -74,7 +80,7 @@ class DeviceCsr:
         import torch
 
         assert row_idx.dtype == torch.int32 and col_idx.dtype == torch.int32
-        dt = SPAM_F64 if vals.dtype == torch.float64 else SPAM_F32
+        dt = {torch.float64: SPAM_F64, torch.float32: SPAM_F32, torch.int64: SPAM_I64}[vals.dtype]
         _lib.ensure_device()
         h = C.c_void_p()
         check(_lib.load().spam_csr_from_sorted_coo(dt, rows, cols, int(col_idx.numel()), C.c_void_p(row_idx.data_ptr()),
@@ -119,15 +125,13 @@ class DeviceCsr:
         offsets = np.empty(rows + 1, dtype=np.uint64)
         indices = np.empty(nnz, dtype=np.uint64)
         vals = np.empty(nnz, dtype=_DT2NP[dt])
-        fn = _lib.load().spam_csr_download_f64 if dt == SPAM_F64 else _lib.load().spam_csr_download_f32
-        check(fn(self._h, _vp(offsets), _vp(indices), _vp(vals)))
+        check(_typed("csr_download", dt)(self._h, _vp(offsets), _vp(indices), _vp(vals)))
         return offsets, indices, vals
 
     def download_row_ptr(self) -> np.ndarray:
         rows, _, _, dt, _ = self.dims()
         offsets = np.empty(rows + 1, dtype=np.uint64)
-        fn = _lib.load().spam_csr_download_f64 if dt == SPAM_F64 else _lib.load().spam_csr_download_f32
-        check(fn(self._h, _vp(offsets), None, None))
+        check(_typed("csr_download", dt)(self._h, _vp(offsets), None, None))
         return offsets
 
     # -- products -----------------------------------------------------------------------------
@@ -162,8 +166,7 @@ class DeviceCsr:
         if x.size != cols:
             raise SpamError(1, f"x has {x.size} entries, A has {cols} columns")
         y = np.empty(rows, dtype=_DT2NP[dt])
-        fn = _lib.load().spam_spmv_f64 if dt == SPAM_F64 else _lib.load().spam_spmv_f32
-        check(fn(self._h, _vp(x), _vp(y)))
+        check(_typed("spmv", dt)(self._h, _vp(x), _vp(y)))
         return y
 
     def spgemm(self, rhs: "DeviceCsr", sort_rows=False):
@@ -173,6 +176,37 @@ class DeviceCsr:
         st = SpgemmStats()
         check(_lib.load().spam_spgemm_dev(self._h, rhs._h, int(sort_rows), C.byref(h), C.byref(st)))
         return DeviceCsr(h), st.asdict()
+
+    def spgemm_symbolic(self, rhs: "DeviceCsr"):
+        """Phase 1 (flop count + symbolic + scan): returns (plan handle, nnz(C)).  Reads row_ptr / col_idx only, so it
+        can run while B's values are still arriving (multi-GPU: overlap with the all-gather of vals)."""
+        plan = C.c_void_p()
+        nnz = C.c_uint64()
+        check(_lib.load().spam_spgemm_symbolic(self._h, rhs._h, C.byref(plan), C.byref(nnz)))
+        return plan, nnz.value
+
+    @staticmethod
+    def spgemm_numeric(plan, sort_rows=False):
+        """Phase 2 on a plan from spgemm_symbolic: returns (DeviceCsr, stats dict); the plan is consumed and freed."""
+        L = _lib.load()
+        h = C.c_void_p()
+        st = SpgemmStats()
+        try:
+            check(L.spam_spgemm_numeric_dev(plan, int(sort_rows), C.byref(h)))
+            check(L.spam_spgemm_plan_stats(plan, C.byref(st)))
+        finally:
+            L.spam_spgemm_plan_free(plan)
+        return DeviceCsr(h), st.asdict()
+
+    def rank_step(self, rhs: "DeviceCsr", rank: int, world: int, row_overhead: int = 2300, sort_rows=False):
+        """This rank's block of C = self * rhs on `world` GPUs (spam_spgemm_rank_step): returns (C block or None,
+        stats dict, (row_lo, row_hi))."""
+        h = C.c_void_p()
+        st = SpgemmStats()
+        lo, hi = C.c_uint64(), C.c_uint64()
+        check(_lib.load().spam_spgemm_rank_step(self._h, rhs._h, rank, world, row_overhead, int(sort_rows), C.byref(h),
+                                                C.byref(lo), C.byref(hi), C.byref(st)))
+        return (DeviceCsr(h) if h.value else None), st.asdict(), (lo.value, hi.value)
 
     def rows_to_parts(self, rhs: "DeviceCsr", nparts: int):
         rows = self.dims()[0]
@@ -311,7 +345,7 @@ class CsrMatrix:
             offsets = np.empty(self._rows + 1, dtype=np.uint64)
             indices = np.empty(nnz.value, dtype=np.uint64)
             vals = np.empty(nnz.value, dtype=self.vals.dtype)
-            fn = L.spam_spgemm_numeric_f64 if self.vals.dtype == np.float64 else L.spam_spgemm_numeric_f32
+            fn = _typed("spgemm_numeric", _NP2DT[self.vals.dtype])
             order = 1 if sort_output else (2 if reference_order else 0)
             check(fn(plan, order, _vp(offsets), _vp(indices), _vp(vals)))
         finally:

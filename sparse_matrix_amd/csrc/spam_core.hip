@@ -3,6 +3,7 @@
 // Reference counterpart: the CsrMatrix container itself (spam_csr/src/lib.rs:25-32) and its invariants
 // (lib.rs:47-81).  Nothing here is arithmetic; the kernels only narrow/widen indices (usize <-> u32, the
 // truncation the reference performs per product at mul_hash.rs:92,157 happens ONCE here) and validate.
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -181,6 +182,13 @@ __global__ __launch_bounds__(1024) void invariant6_long_kernel(const uint64_t* _
   if (b) atomicOr(bad, b);
 }
 
+// float4 grid-stride copy: the measured ceiling for streaming kernels on this device (spam_hip_copy_gbps)
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ in, float4* __restrict__ out, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = in[i];
+}
+
 static int check_aligned(const void* p, const char* what) {
   if (((uintptr_t)p & 15) != 0) return set_error(SPAM_E_INVALID, "%s is not 16-byte aligned", what);
   return SPAM_OK;
@@ -319,6 +327,34 @@ int spam_hip_trim(void) {
   return SPAM_OK;
 }
 
+int spam_hip_copy_gbps(uint64_t bytes, int reps, double* gbps_out) {
+  clear_error();
+  if (!gbps_out || bytes < 16 || reps < 1) return set_error(SPAM_E_INVALID, "bad argument");
+  hipStream_t s = stream();
+  const uint64_t n = bytes / 16;
+  DevBuf a, b;
+  SPAM_TRY(a.alloc(n * 16));
+  SPAM_TRY(b.alloc(n * 16));
+  SPAM_HIP_TRY(hipMemsetAsync(a.p, 1, n * 16, s));
+  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256ull * 64);
+  hipEvent_t e0, e1;
+  SPAM_HIP_TRY(hipEventCreate(&e0));
+  SPAM_HIP_TRY(hipEventCreate(&e1));
+  stream_copy_kernel<<<grid, 256, 0, s>>>(a.as<float4>(), b.as<float4>(), n);  // warm-up
+  (void)hipEventRecord(e0, s);
+  for (int r = 0; r < reps; ++r) stream_copy_kernel<<<grid, 256, 0, s>>>(a.as<float4>(), b.as<float4>(), n);
+  (void)hipEventRecord(e1, s);
+  hipError_t le = hipGetLastError();
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (le != hipSuccess) return set_error(SPAM_E_HIP, "stream_copy_kernel: %s", hipGetErrorString(le));
+  *gbps_out = 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9;  // read + write
+  return SPAM_OK;
+}
+
 int spam_hip_synchronize(void) {
   clear_error();
   SPAM_HIP_TRY(hipStreamSynchronize(stream()));
@@ -333,13 +369,17 @@ int spam_csr_upload_f32(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64
                         const float* vals, int is_sorted, spam_csr** out) {
   return upload_impl(SPAM_F32, rows, cols, nnz, offsets, indices, vals, is_sorted, out);
 }
+int spam_csr_upload_i64(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t* offsets, const uint64_t* indices,
+                        const int64_t* vals, int is_sorted, spam_csr** out) {
+  return upload_impl(SPAM_I64, rows, cols, nnz, offsets, indices, vals, is_sorted, out);
+}
 
 int spam_csr_from_device(int dtype, uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t* d_row_ptr,
                          const uint32_t* d_col_idx, const void* d_vals, int is_sorted, spam_csr** out) {
   clear_error();
   if (!out) return set_error(SPAM_E_INVALID, "out is NULL");
   *out = nullptr;
-  if (dtype != SPAM_F32 && dtype != SPAM_F64) return set_error(SPAM_E_INVALID, "bad dtype %d", dtype);
+  if (dtype != SPAM_F32 && dtype != SPAM_F64 && dtype != SPAM_I64) return set_error(SPAM_E_INVALID, "bad dtype %d", dtype);
   if (rows == 0 || cols == 0) return set_error(SPAM_E_INVALID, "rows and cols are NonZeroUsize (lib.rs:27-28)");
   if (cols >= 0xFFFFFFFFull) return set_error(SPAM_E_INDEX_RANGE, "cols must be < u32::MAX (mul_hash.rs:12)");
   if (rows >= 0xFFFFFFFFull) return set_error(SPAM_E_UNSUPPORTED, "rows >= 2^32-1 not supported");
@@ -493,6 +533,9 @@ int spam_csr_download_f64(const spam_csr* m, uint64_t* offsets, uint64_t* indice
 }
 int spam_csr_download_f32(const spam_csr* m, uint64_t* offsets, uint64_t* indices, float* vals) {
   return download_impl<float>(m, SPAM_F32, offsets, indices, vals);
+}
+int spam_csr_download_i64(const spam_csr* m, uint64_t* offsets, uint64_t* indices, int64_t* vals) {
+  return download_impl<int64_t>(m, SPAM_I64, offsets, indices, vals);
 }
 
 int spam_csr_invariants(const spam_csr* m, int* ok) {

@@ -185,7 +185,8 @@ extern "C" int spam_csr_add(const spam_csr* a, const spam_csr* b, int subtract, 
     }
   const spam_csr* aa = as ? as : a;
   const spam_csr* bb = bs ? bs : b;
-  int e = a->dtype == SPAM_F64 ? add_typed<double>(aa, bb, subtract, out) : add_typed<float>(aa, bb, subtract, out);
+  int e = SPAM_DISPATCH_DTYPE(a->dtype, add_typed<double>(aa, bb, subtract, out), add_typed<float>(aa, bb, subtract, out),
+                              add_typed<i64w>(aa, bb, subtract, out));
   if (e == SPAM_OK) (void)hipStreamSynchronize(stream());
   if (as) spam_csr_free(as);
   if (bs) spam_csr_free(bs);

@@ -101,6 +101,12 @@ struct spam_csr {
 namespace spam {
 
 inline size_t dtype_size(int dtype) { return dtype == SPAM_F32 ? 4 : 8; }
+// SPAM_I64 values are computed on their bit pattern as unsigned 64-bit integers: unsigned arithmetic wraps, which IS
+// Wrapping<i64>'s two's-complement behaviour (and keeps the kernels free of signed-overflow undefined behaviour)
+typedef unsigned long long i64w;
+// run f.template operator()<T>() for the value type of a handle
+#define SPAM_DISPATCH_DTYPE(dtype, CALL_F64, CALL_F32, CALL_I64) \
+  ((dtype) == SPAM_F64 ? (CALL_F64) : (dtype) == SPAM_F32 ? (CALL_F32) : (CALL_I64))
 
 // ---- device primitives (spam_scan.hip) ----------------------------------------------------------
 // out[0] = 0, out[i+1] = sum(in[0..i]) for i < n, u64 accumulation (checked_inclusive_scan's shape,

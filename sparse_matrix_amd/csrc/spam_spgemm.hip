@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void bin_rows_kernel(const KeyT* __restrict__ 
 // LDS float add.  ds_add_f64 runs at ~2.7 lane-ops/clk/CU, but ds_add_f32 only at 0.38 on gfx950 while a CAS loop on
 // the bit pattern reaches 2.4 (tools/lds_atomic_bench.hip, profiles/r01_lds_atomic_microbench.txt) — so f32 uses the loop.
 __device__ __forceinline__ void lds_add(double* p, double v) { atomicAdd(p, v); }
+__device__ __forceinline__ void lds_add(i64w* p, i64w v) { atomicAdd(p, v); }  // ds_add_u64: wrapping, order-independent
 __device__ __forceinline__ void lds_add(float* p, float v) {
   uint32_t* q = (uint32_t*)p;
   uint32_t old = *q, assumed;
@@ -836,11 +837,20 @@ __device__ __forceinline__ double shfl_val(double v, uint32_t src_lane) {
 __device__ __forceinline__ float shfl_val(float v, uint32_t src_lane) {
   return __builtin_bit_cast(float, shfl_u32(__builtin_bit_cast(uint32_t, v), src_lane));
 }
+__device__ __forceinline__ i64w shfl_val(i64w v, uint32_t src_lane) {
+  const uint32_t lo = shfl_u32((uint32_t)v, src_lane), hi = shfl_u32((uint32_t)(v >> 32), src_lane);
+  return ((i64w)hi << 32) | (i64w)lo;
+}
 __device__ __forceinline__ double readlane_val(double v, uint32_t src_lane) {
   const long long b = __builtin_bit_cast(long long, v);
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, (int)src_lane);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), (int)src_lane);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+__device__ __forceinline__ i64w readlane_val(i64w v, uint32_t src_lane) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src_lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src_lane);
+  return ((i64w)hi << 32) | (i64w)lo;
 }
 __device__ __forceinline__ float readlane_val(float v, uint32_t src_lane) {
   return __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, v), (int)src_lane));
@@ -2081,10 +2091,10 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
       SPAM_TRY(p->bs_val.alloc(b->nnz * dtype_size(b->dtype)));
       SPAM_HIP_TRY(hipMemcpyAsync(p->bs_col.p, b->col_idx, b->nnz * 4, hipMemcpyDeviceToDevice, s));
       SPAM_HIP_TRY(hipMemcpyAsync(p->bs_val.p, b->vals, b->nnz * dtype_size(b->dtype), hipMemcpyDeviceToDevice, s));
-      if (b->dtype == SPAM_F64)
-        SPAM_TRY(sort_rows_typed<double>(b->rows, b->cols, b->row_ptr, p->bs_col.as<uint32_t>(), p->bs_val.as<double>(), s));
-      else
-        SPAM_TRY(sort_rows_typed<float>(b->rows, b->cols, b->row_ptr, p->bs_col.as<uint32_t>(), p->bs_val.as<float>(), s));
+      SPAM_TRY(SPAM_DISPATCH_DTYPE(
+          b->dtype, sort_rows_typed<double>(b->rows, b->cols, b->row_ptr, p->bs_col.as<uint32_t>(), p->bs_val.as<double>(), s),
+          sort_rows_typed<float>(b->rows, b->cols, b->row_ptr, p->bs_col.as<uint32_t>(), p->bs_val.as<float>(), s),
+          sort_rows_typed<i64w>(b->rows, b->cols, b->row_ptr, p->bs_col.as<uint32_t>(), p->bs_val.as<i64w>(), s)));
       p->b_col = p->bs_col.as<uint32_t>();
       p->b_val = p->bs_val.p;
     }
@@ -2335,7 +2345,8 @@ static int numeric_dev_impl(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out
   if (!p || !c_out) return set_error(SPAM_E_INVALID, "NULL argument");
   *c_out = nullptr;
   if (p->numeric_done) return set_error(SPAM_E_INVALID, "plan already consumed by a numeric call");
-  return p->a->dtype == SPAM_F64 ? numeric_typed<double>(p, sort_rows, c_out) : numeric_typed<float>(p, sort_rows, c_out);
+  return SPAM_DISPATCH_DTYPE(p->a->dtype, numeric_typed<double>(p, sort_rows, c_out), numeric_typed<float>(p, sort_rows, c_out),
+                             numeric_typed<i64w>(p, sort_rows, c_out));
 }
 
 }  // namespace spam
@@ -2359,7 +2370,7 @@ int spam_spgemm_numeric_dev(spam_spgemm_plan* plan, int sort_rows, spam_csr** c_
 int spam_spgemm_numeric_f64(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out, uint64_t* indices_out,
                             double* vals_out) {
   clear_error();
-  if (plan && plan->a->dtype != SPAM_F64) return set_error(SPAM_E_DTYPE, "plan holds f32 matrices");
+  if (plan && plan->a->dtype != SPAM_F64) return set_error(SPAM_E_DTYPE, "plan does not hold f64 matrices");
   spam_csr* c = nullptr;
   SPAM_TRY(numeric_dev_impl(plan, sort_rows, &c));
   int e = spam_csr_download_f64(c, offsets_out, indices_out, vals_out);
@@ -2370,10 +2381,21 @@ int spam_spgemm_numeric_f64(spam_spgemm_plan* plan, int sort_rows, uint64_t* off
 int spam_spgemm_numeric_f32(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out, uint64_t* indices_out,
                             float* vals_out) {
   clear_error();
-  if (plan && plan->a->dtype != SPAM_F32) return set_error(SPAM_E_DTYPE, "plan holds f64 matrices");
+  if (plan && plan->a->dtype != SPAM_F32) return set_error(SPAM_E_DTYPE, "plan does not hold f32 matrices");
   spam_csr* c = nullptr;
   SPAM_TRY(numeric_dev_impl(plan, sort_rows, &c));
   int e = spam_csr_download_f32(c, offsets_out, indices_out, vals_out);
+  spam_csr_free(c);
+  return e;
+}
+
+int spam_spgemm_numeric_i64(spam_spgemm_plan* plan, int sort_rows, uint64_t* offsets_out, uint64_t* indices_out,
+                            int64_t* vals_out) {
+  clear_error();
+  if (plan && plan->a->dtype != SPAM_I64) return set_error(SPAM_E_DTYPE, "plan does not hold i64 matrices");
+  spam_csr* c = nullptr;
+  SPAM_TRY(numeric_dev_impl(plan, sort_rows, &c));
+  int e = spam_csr_download_i64(c, offsets_out, indices_out, vals_out);
   spam_csr_free(c);
   return e;
 }
@@ -2384,10 +2406,9 @@ int spam_csr_sort_rows(spam_csr* m) {
   if (m->is_sorted) return SPAM_OK;
   if (!m->owns_col_val) return set_error(SPAM_E_INVALID, "cannot sort a borrowed matrix in place (views, spam_csr_from_device)");
   hipStream_t s = stream();
-  if (m->dtype == SPAM_F64)
-    SPAM_TRY(sort_rows_typed<double>(m->rows, m->cols, m->row_ptr, m->col_idx, (double*)m->vals, s));
-  else
-    SPAM_TRY(sort_rows_typed<float>(m->rows, m->cols, m->row_ptr, m->col_idx, (float*)m->vals, s));
+  SPAM_TRY(SPAM_DISPATCH_DTYPE(m->dtype, sort_rows_typed<double>(m->rows, m->cols, m->row_ptr, m->col_idx, (double*)m->vals, s),
+                               sort_rows_typed<float>(m->rows, m->cols, m->row_ptr, m->col_idx, (float*)m->vals, s),
+                               sort_rows_typed<i64w>(m->rows, m->cols, m->row_ptr, m->col_idx, (i64w*)m->vals, s)));
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   m->is_sorted = 1;
   if (m->spmv_plan) {  // the hot-column remap mirrors col_idx
@@ -2446,6 +2467,25 @@ static int rows_to_parts_impl(const spam_csr* a, const spam_csr* b, uint64_t npa
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (htot[1]) return set_error(SPAM_E_OVERFLOW, "intermediate-product count overflows usize (mul_hash.rs:47-48)");
   return SPAM_OK;
+}
+
+int spam_spgemm_rank_step(const spam_csr* a_full, const spam_csr* b_full, uint64_t rank, uint64_t world,
+                          uint64_t row_overhead, int sort_rows, spam_csr** c_block, uint64_t* row_lo, uint64_t* row_hi,
+                          spam_spgemm_stats* stats) {
+  clear_error();
+  if (!c_block || !row_lo || !row_hi) return set_error(SPAM_E_INVALID, "NULL output");
+  *c_block = nullptr;
+  if (world == 0 || rank >= world) return set_error(SPAM_E_INVALID, "rank %llu outside world %llu", (unsigned long long)rank, (unsigned long long)world);
+  std::vector<uint64_t> offs(world + 1);
+  SPAM_TRY(rows_to_parts_impl(a_full, b_full, world, row_overhead, nullptr, offs.data()));
+  *row_lo = offs[rank], *row_hi = offs[rank + 1];
+  if (stats) *stats = spam_spgemm_stats{};
+  if (*row_hi <= *row_lo) return SPAM_OK;  // an empty block (more ranks than non-empty rows): *c_block stays NULL
+  spam_csr* blk = nullptr;
+  SPAM_TRY(spam_csr_row_block(a_full, *row_lo, *row_hi, &blk));
+  const int e = spam_spgemm_dev(blk, b_full, sort_rows, c_block, stats);
+  spam_csr_free(blk);
+  return e;
 }
 
 int spam_rows_to_parts(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t* row_flops_out,

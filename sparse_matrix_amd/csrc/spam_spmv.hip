@@ -135,6 +135,11 @@ struct Vec4<float> {
   typedef float type __attribute__((ext_vector_type(4)));
   static constexpr int N = 4;
 };
+template <>
+struct Vec4<i64w> {
+  typedef i64w type __attribute__((ext_vector_type(2)));
+  static constexpr int N = 2;
+};
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Explicit global address space: pointers that a kernel reads from a descriptor in memory are generic to the
 // compiler (flat_load, which also occupies the LDS counter and is waited for one at a time); the tile body takes
@@ -1688,22 +1693,24 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
   return SPAM_OK;
 }
 
+template <class T>
+static int spmv_launch_t(const spam_csr* a, const void* d_x, void* d_y, hipStream_t s) {
+  if (a->row_ptr32) return spmv_typed<T, uint32_t>(a, a->row_ptr32, (const T*)d_x, (T*)d_y, s);
+  return spmv_typed<T, uint64_t>(a, a->row_ptr, (const T*)d_x, (T*)d_y, s);
+}
 int spmv_launch(const spam_csr* a, const void* d_x, void* d_y, hipStream_t s) {
-  if (a->dtype == SPAM_F64) {
-    if (a->row_ptr32) return spmv_typed<double, uint32_t>(a, a->row_ptr32, (const double*)d_x, (double*)d_y, s);
-    return spmv_typed<double, uint64_t>(a, a->row_ptr, (const double*)d_x, (double*)d_y, s);
-  }
-  if (a->row_ptr32) return spmv_typed<float, uint32_t>(a, a->row_ptr32, (const float*)d_x, (float*)d_y, s);
-  return spmv_typed<float, uint64_t>(a, a->row_ptr, (const float*)d_x, (float*)d_y, s);
+  return SPAM_DISPATCH_DTYPE(a->dtype, spmv_launch_t<double>(a, d_x, d_y, s), spmv_launch_t<float>(a, d_x, d_y, s),
+                             spmv_launch_t<i64w>(a, d_x, d_y, s));
 }
 
+template <class T>
+static int spmv_prepare_t(spam_csr* a, const void* d_x, hipStream_t s) {
+  if (a->row_ptr32) return prepare_typed<T, uint32_t>(a, a->row_ptr32, (const T*)d_x, s);
+  return prepare_typed<T, uint64_t>(a, a->row_ptr, (const T*)d_x, s);
+}
 static int spmv_prepare(spam_csr* a, const void* d_x, hipStream_t s) {
-  if (a->dtype == SPAM_F64) {
-    if (a->row_ptr32) return prepare_typed<double, uint32_t>(a, a->row_ptr32, (const double*)d_x, s);
-    return prepare_typed<double, uint64_t>(a, a->row_ptr, (const double*)d_x, s);
-  }
-  if (a->row_ptr32) return prepare_typed<float, uint32_t>(a, a->row_ptr32, (const float*)d_x, s);
-  return prepare_typed<float, uint64_t>(a, a->row_ptr, (const float*)d_x, s);
+  return SPAM_DISPATCH_DTYPE(a->dtype, spmv_prepare_t<double>(a, d_x, s), spmv_prepare_t<float>(a, d_x, s),
+                             spmv_prepare_t<i64w>(a, d_x, s));
 }
 
 template <class T>
@@ -1733,6 +1740,9 @@ int spam_spmv_f64(const spam_csr* a, const double* x_host, double* y_host) {
 }
 int spam_spmv_f32(const spam_csr* a, const float* x_host, float* y_host) {
   return spmv_host<float>(a, SPAM_F32, x_host, y_host);
+}
+int spam_spmv_i64(const spam_csr* a, const int64_t* x_host, int64_t* y_host) {
+  return spmv_host<i64w>(a, SPAM_I64, (const i64w*)x_host, (i64w*)y_host);
 }
 int spam_spmv_plan_info(const spam_csr* a, uint64_t* hot_columns, double* hot_cover, uint64_t* tiles) {
   clear_error();
@@ -1780,8 +1790,9 @@ int spam_csr_values_changed(spam_csr* a) {
   std::lock_guard<std::mutex> lk(a->plan_mu);
   SpmvPlan* p = a->spmv_plan;
   if (!p || !p->sliced) return SPAM_OK;  // the plain path reads the values where they are
-  if (a->dtype == SPAM_F64) return sliced_refresh_values<double>(a, p->sliced, stream());
-  return sliced_refresh_values<float>(a, p->sliced, stream());
+  return SPAM_DISPATCH_DTYPE(a->dtype, sliced_refresh_values<double>(a, p->sliced, stream()),
+                             sliced_refresh_values<float>(a, p->sliced, stream()),
+                             sliced_refresh_values<i64w>(a, p->sliced, stream()));
 }
 
 }  // extern "C"

@@ -3,10 +3,24 @@ over xGMI; "gloo" for CPU tests and single-GPU rehearsals).
 
 The reference is single-process; its only partition is rows_to_threads (spam_csr/src/mul_hash.rs:38-64),
 contiguous row ranges balanced by intermediate products.  The same rule cuts A across GPUs (tnum = world
-size).  C's rows depend on the matching rows of A and ALL of B, so the one exchange step is an all-gather
-of B's CSR arrays (row blocks are unequal: shards are padded to the longest and moved by one all-gather per array);
-nothing is reduced and C stays row-sharded.  Everything here works on torch tensors of any device, so the
-logic is exercised on CPU with gloo (tests/test_dist_cpu.py).
+size).  C's rows depend on the matching rows of A and ALL of B, so the one exchange step is an all-gather-v
+of B's three CSR arrays; nothing is reduced and C stays row-sharded.
+
+Exchange.  Row shards are unequal, so the all-gather-v is an all-to-all in which every rank offers its shard to
+every peer and receives each peer's shard at its final offset of the gathered array: on RCCL that is one
+grouped ncclSend / ncclRecv per pair (xGMI is point-to-point, so every peer link carries exactly one shard,
+concurrently), no padding and no copy afterwards — bytes received = the unpadded size of B.  The collectives are
+issued asynchronously in the order row_ptr, col_idx, vals; the symbolic phase needs only the first two, so the
+transfer of vals overlaps with it (`allgather_csr(..., async_vals=True)`).  Backends without all_to_all
+(gloo on CPU) take one broadcast per source and array — decided from the backend before any collective is
+issued, never by catching an error in the middle of one.
+
+Initial distribution.  With equal row blocks an R-MAT shard holds up to 44 % of the entries (the first eighth of
+the rows, a + b = 0.76 per level); `nnz_balanced_blocks` cuts the rows so that every rank starts with about the
+same number of entries, which is what bounds the slowest link of the exchange.
+
+Everything here works on torch tensors of any device, so the logic is exercised on CPU with gloo
+(tests/test_dist_cpu.py).
 """
 from __future__ import annotations
 
@@ -14,72 +28,119 @@ import torch
 
 
 def equal_row_block(n_rows: int, rank: int, world: int) -> tuple[int, int]:
-    """Initial distribution: rank r generates / holds rows [r*n/world, (r+1)*n/world)."""
+    """Rank r holds rows [r*n/world, (r+1)*n/world)."""
     return rank * n_rows // world, (rank + 1) * n_rows // world
 
 
-def allgather_csr(row_ptr: torch.Tensor, col_idx: torch.Tensor, vals: torch.Tensor, n_rows: int, rank: int,
-                  world: int, dist=None):
-    """All-gather-v of equal_row_block-distributed CSR blocks into the full matrix on every rank.
+def equal_row_blocks(n_rows: int, world: int) -> list[int]:
+    return [r * n_rows // world for r in range(world)] + [n_rows]
 
-    row_ptr int64[rows_local+1] (block-local offsets starting at 0), col_idx int32[nnz_local], vals[nnz_local].
-    Returns (row_ptr int64[n_rows+1], col_idx, vals) with row_ptr globalised by each source's offset.
-    Traffic per rank: receives nnz_total*(4+sizeof T) + n_rows*8 bytes, sends its own block once per peer.
+
+def nnz_balanced_blocks(bucket_nnz, bucket_rows: int, n_rows: int, world: int) -> list[int]:
+    """Row offsets [0, ..., n_rows] of `world` contiguous blocks holding about the same number of entries each;
+    bucket_nnz[i] = entries in rows [i*bucket_rows, (i+1)*bucket_rows) (block edges fall on bucket edges)."""
+    c = torch.as_tensor(bucket_nnz).to(torch.int64).cpu()
+    ps = torch.zeros(c.numel() + 1, dtype=torch.int64)
+    torch.cumsum(c, 0, out=ps[1:])
+    total = int(ps[-1].item())
+    offs = [0]
+    for t in range(1, world):
+        b = int(torch.searchsorted(ps, torch.tensor([total * t // world], dtype=torch.int64), right=False).item())
+        b = max(offs[-1] // bucket_rows, min(b, c.numel()))
+        offs.append(min(b * bucket_rows, n_rows))
+    offs.append(n_rows)
+    return offs
+
+
+def _has_all_to_all(dist) -> bool:
+    """Capability from the backend name, agreed by construction on every rank (no probing collective)."""
+    return str(dist.get_backend()).lower() == "nccl"
+
+
+class Gathered:
+    """Result of allgather_csr: the full arrays plus what the exchange moved."""
+
+    def __init__(self, rp, col, val, pending, stats):
+        self.row_ptr, self.col_idx, self.vals = rp, col, val
+        self._pending = pending
+        self.stats = stats
+
+    def wait_structure(self):
+        """row_ptr and col_idx have arrived (the current stream waits; the host does not block on NCCL)."""
+        for w in self._pending[:2]:
+            if w is not None:
+                w.wait()
+        self._pending[0] = self._pending[1] = None
+
+    def wait_values(self):
+        w = self._pending[2]
+        if w is not None:
+            w.wait()
+        self._pending[2] = None
+
+    def wait(self):
+        self.wait_structure()
+        self.wait_values()
+        return self.row_ptr, self.col_idx, self.vals
+
+
+def allgather_csr(row_ptr: torch.Tensor, col_idx: torch.Tensor, vals: torch.Tensor, row_offsets: list[int], rank: int,
+                  world: int, dist=None, async_vals: bool = False) -> Gathered:
+    """All-gather-v of row-block-distributed CSR shards into the full matrix on every rank.
+
+    row_offsets[r] .. row_offsets[r+1] = the rows rank r holds (any contiguous split); row_ptr int64[rows_local+1]
+    (block-local offsets starting at 0), col_idx int32[nnz_local], vals[nnz_local].  Returns a `Gathered` whose
+    row_ptr is globalised by each source's entry offset.  With async_vals the caller gets control back while vals
+    is still in flight: call wait_structure(), run the symbolic phase, then wait_values().
     """
     dev = col_idx.device
+    n_rows = row_offsets[-1]
     if world == 1 or dist is None:
-        return row_ptr, col_idx, vals
+        nb = int(col_idx.numel()) * (col_idx.element_size() + vals.element_size()) + (n_rows + 1) * 8
+        return Gathered(row_ptr, col_idx, vals, [None, None, None], {"bytes_received": 0, "bytes_unpadded": nb, "mode": "local"})
     nnz_local = int(col_idx.numel())
     sizes = torch.zeros(world, dtype=torch.int64, device=dev)
     sizes[rank] = nnz_local
     dist.all_reduce(sizes)
     sizes_h = sizes.cpu().tolist()
-    starts_h = [0] * world
-    for r in range(1, world):
-        starts_h[r] = starts_h[r - 1] + sizes_h[r - 1]
-    nnz_tot = starts_h[-1] + sizes_h[-1]
+    starts_h = [0] * (world + 1)
+    for r in range(world):
+        starts_h[r + 1] = starts_h[r] + sizes_h[r]
+    nnz_tot = starts_h[world]
     col = torch.empty(nnz_tot, dtype=col_idx.dtype, device=dev)
     val = torch.empty(nnz_tot, dtype=vals.dtype, device=dev)
     rp = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
-    lo, hi = equal_row_block(n_rows, rank, world)
-    s0 = starts_h[rank]
+    lo, hi = row_offsets[rank], row_offsets[rank + 1]
     rp[n_rows] = nnz_tot
-    try:
-        # one padded all-gather per array (3 collectives: on xGMI every peer link carries one shard concurrently),
-        # then each shard is copied to its place; falls back to per-source broadcasts where the backend lacks it
-        maxn = max(sizes_h)
-        maxr = max(equal_row_block(n_rows, r, world)[1] - equal_row_block(n_rows, r, world)[0] for r in range(world))
-        pc = torch.zeros(maxn, dtype=col_idx.dtype, device=dev)
-        pv = torch.zeros(maxn, dtype=vals.dtype, device=dev)
-        pr = torch.zeros(maxr, dtype=torch.int64, device=dev)
-        pc[:nnz_local] = col_idx
-        pv[:nnz_local] = vals
-        pr[:hi - lo] = row_ptr[:-1] + s0  # row_ptr fix-up by the source rank's global nnz offset
-        gc = torch.empty(world * maxn, dtype=col_idx.dtype, device=dev)
-        gv = torch.empty(world * maxn, dtype=vals.dtype, device=dev)
-        gr = torch.empty(world * maxr, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(gc, pc)
-        dist.all_gather_into_tensor(gv, pv)
-        dist.all_gather_into_tensor(gr, pr)
-        for r in range(world):
-            r0, r1 = equal_row_block(n_rows, r, world)
-            a0, a1 = starts_h[r], starts_h[r] + sizes_h[r]
-            col[a0:a1] = gc[r * maxn:r * maxn + sizes_h[r]]
-            val[a0:a1] = gv[r * maxn:r * maxn + sizes_h[r]]
-            rp[r0:r1] = gr[r * maxr:r * maxr + (r1 - r0)]
-    except (RuntimeError, NotImplementedError):
-        col[s0:s0 + nnz_local] = col_idx
-        val[s0:s0 + nnz_local] = vals
-        rp[lo:hi] = row_ptr[:-1] + s0
-        for r in range(world):  # unequal shards: one broadcast per source and array
-            r0, r1 = equal_row_block(n_rows, r, world)
-            a0, a1 = starts_h[r], starts_h[r] + sizes_h[r]
-            if a1 > a0:
-                dist.broadcast(col[a0:a1], src=r)
-                dist.broadcast(val[a0:a1], src=r)
-            if r1 > r0:
-                dist.broadcast(rp[r0:r1], src=r)
-    return rp, col, val
+    my_rp = row_ptr[:-1] + starts_h[rank]  # row_ptr fix-up by the source rank's global entry offset
+    other_rows = n_rows - (hi - lo)
+    other_nnz = nnz_tot - nnz_local
+    stats = {"bytes_received": other_rows * 8 + other_nnz * (col.element_size() + val.element_size()),
+             "bytes_unpadded": other_rows * 8 + other_nnz * (col.element_size() + val.element_size())}
+    pending = [None, None, None]
+    if _has_all_to_all(dist):
+        stats["mode"] = "all_to_all (grouped send/recv, one shard per peer link)"
+
+        def a2a(out_full, bounds, mine):
+            outs = [out_full[bounds[r]:bounds[r + 1]] for r in range(world)]
+            return dist.all_to_all(outs, [mine] * world, async_op=True)
+
+        pending[0] = a2a(rp, row_offsets, my_rp.contiguous())
+        pending[1] = a2a(col, starts_h, col_idx)
+        pending[2] = a2a(val, starts_h, vals)
+    else:
+        stats["mode"] = "broadcast per source (backend without all_to_all)"
+        rp[lo:hi] = my_rp
+        col[starts_h[rank]:starts_h[rank + 1]] = col_idx
+        val[starts_h[rank]:starts_h[rank + 1]] = vals
+        for arr, bounds in ((rp, row_offsets), (col, starts_h), (val, starts_h)):
+            for r in range(world):  # unequal shards: one broadcast per source and array
+                if bounds[r + 1] > bounds[r]:
+                    dist.broadcast(arr[bounds[r]:bounds[r + 1]], src=r)
+    g = Gathered(rp, col, val, pending, stats)
+    if not async_vals:
+        g.wait()
+    return g
 
 
 def rows_to_parts_host(row_flops: torch.Tensor, nparts: int) -> list[int]:
@@ -112,7 +173,7 @@ def balanced_row_blocks(row_flops, nparts: int, row_overhead: int = ROW_OVERHEAD
 
 def allgather_vector(x_local: torch.Tensor, n: int, rank: int, world: int, dist=None) -> torch.Tensor:
     """Row-sharded SpMV needs all of x: every rank owns x[equal_row_block] and receives the rest (one padded
-    all-gather; 8 B * n / world per peer link)."""
+    all-gather; 8 B * n / world per peer link; equal blocks differ by at most one element)."""
     if world == 1 or dist is None:
         return x_local
     blocks = [equal_row_block(n, r, world) for r in range(world)]

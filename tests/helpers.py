@@ -71,3 +71,19 @@ def spgemm_rows_vs_oracle(oracle, dA, dB, C, a_host, b_host, row_lo, target_prod
         if len(want[2]):
             assert float(np.max(np.abs(v2 - want[2]) / np.abs(want[2]))) <= rtol
     return r1, float(ps[r1] - ps[row_lo]), len(want[1])
+
+
+def assert_csr_exact(got, want, sorted_output):
+    """Integer values (Wrapping<i64>): everything bit-exact — row_ptr, col_idx (as stored when sorted or in reference
+    order, per-row sets otherwise) and the values themselves (integer sums do not depend on the summation order)."""
+    go, gi, gv = got
+    wo, wi, wv = want
+    assert np.array_equal(np.asarray(go, dtype=np.uint64), np.asarray(wo, dtype=np.uint64)), "row_ptr differs"
+    if sorted_output:
+        assert np.array_equal(np.asarray(gi, dtype=np.uint64), np.asarray(wi, dtype=np.uint64)), "col_idx differs"
+        assert np.array_equal(gv, wv), "values differ"
+    else:
+        gi_s, gv_s = sort_rows(go, gi, gv)
+        wi_s, wv_s = sort_rows(wo, wi, wv)
+        assert np.array_equal(gi_s, wi_s), "per-row column sets differ"
+        assert np.array_equal(gv_s, wv_s), "values differ"

@@ -32,11 +32,25 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         n = 1 << SCALE
-        lo, hi = spdist.equal_row_block(n, rank, world)
-        blk = synth.rmat(SCALE, row_range=(lo, hi) if world > 1 else None)
-        rp, col, val = spdist.allgather_csr(blk.row_ptr, blk.col_idx, blk.vals, n, rank, world, dist)
         full = synth.rmat(SCALE)
+        # initial distribution: nnz-balanced row blocks (unequal row counts: the R-MAT head rows are the long ones)
+        bucket = 16
+        counts = (full.row_ptr[bucket::bucket] - full.row_ptr[:-bucket:bucket])
+        offs0 = spdist.nnz_balanced_blocks(counts, bucket, n, world)
+        assert offs0[0] == 0 and offs0[-1] == n and offs0[1] < n // 2, offs0
+        shard_nnz = [int(full.row_ptr[offs0[r + 1]] - full.row_ptr[offs0[r]]) for r in range(world)]
+        assert max(shard_nnz) <= 1.15 * (full.nnz / world), shard_nnz
+        lo, hi = offs0[rank], offs0[rank + 1]
+        blk = synth.rmat(SCALE, row_range=(lo, hi) if world > 1 else None)
+        g = spdist.allgather_csr(blk.row_ptr, blk.col_idx, blk.vals, offs0, rank, world, dist, async_vals=True)
+        g.wait_structure()
+        g.wait_values()
+        rp, col, val = g.wait()
         assert torch.equal(rp, full.row_ptr) and torch.equal(col, full.col_idx) and torch.equal(val, full.vals)
+        # the exchange moves B once: no padding to the longest shard
+        assert g.stats["bytes_received"] <= 1.15 * g.stats["bytes_unpadded"], g.stats
+        other = full.nnz - blk.nnz
+        assert g.stats["bytes_received"] == other * (4 + 8) + (n - (hi - lo)) * 8
         a = (rp.numpy().astype(np.uint64), col.numpy().astype(np.uint64), val.numpy())
         flops, offs_ref = oracle.rows_to_threads(a[0], a[1], a[0], world)
         offs = spdist.rows_to_parts_host(torch.from_numpy(flops.astype(np.int64)), world)
@@ -50,6 +64,8 @@ def _worker(rank, world, port, ret):
         assert np.array_equal(o, wo[mylo:myhi + 1] - wo[mylo]) and np.array_equal(i, wi[s:e]) and np.array_equal(v, wv[s:e])
         # row-sharded SpMV: all-gather x, multiply the local row block, compare with the matching slice of A x
         xfull = synth.dense_vector(n)
+        lo, hi = spdist.equal_row_block(n, rank, world)
+        blk = synth.rmat(SCALE, row_range=(lo, hi))
         xl = xfull[lo:hi].clone()
         xg = spdist.allgather_vector(xl, n, rank, world, dist)
         assert torch.equal(xg, xfull)
@@ -78,3 +94,11 @@ def test_partition_rule_edge_cases():
     assert spdist.rows_to_parts_host(torch.tensor([0, 0, 0]), 2) == [0, 3, 3]
     assert spdist.rows_to_parts_host(torch.tensor([5]), 3) == [0, 0, 0, 1]
     assert spdist.rows_to_parts_host(torch.tensor([1, 1, 1, 1]), 2) == [0, 2, 4]
+
+
+def test_nnz_balanced_blocks_rule():
+    """Block edges fall on bucket edges, are monotone, and split the entries evenly where the buckets allow."""
+    c = torch.tensor([100, 1, 1, 1, 1, 1, 1, 1])
+    assert spdist.nnz_balanced_blocks(c, 4, 32, 2) == [0, 4, 32]
+    assert spdist.nnz_balanced_blocks(torch.ones(8, dtype=torch.int64), 4, 30, 4) == [0, 8, 16, 24, 30]
+    assert spdist.nnz_balanced_blocks(torch.zeros(8, dtype=torch.int64), 4, 32, 3)[-1] == 32

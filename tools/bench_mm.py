@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The reference's bench shape on the GPU path: for every Matrix Market file in a directory, parse it, build
 CsrMatrix::from(dok) (sorted rows) and time m.mul_hash(&m) with unsorted output (gen_bench_mul!,
-spam_csr/src/lib.rs:386-437; benches/mul_hash.rs:6-11 uses ./matrices).  Integer files are run as f64
-(the GPU path serves f32/f64); complex files are skipped.  Prints one JSON line per file.
+spam_csr/src/lib.rs:386-437; benches/mul_hash.rs:6-11 uses ./matrices).  Integer files run as i64 with wrapping
+arithmetic, exactly as the reference benches MatrixType::Integer (lib.rs:421-424); complex files are skipped (CPU path
+only).  Prints one JSON line per file.
 
   python tools/bench_mm.py DIR [--reps 5]
 """
@@ -27,7 +28,7 @@ def main():
         if kind == "complex":
             print(json.dumps({"file": name, "skipped": "complex values: CPU path only"}))
             continue
-        m = CsrMatrix.from_dok((rows, cols), ents, dtype=np.float64)
+        m = CsrMatrix.from_dok((rows, cols), ents, dtype=np.int64 if kind == "integer" else np.float64)
         d = m.device()
         ts, st = [], None
         for _ in range(args.reps + 1):
