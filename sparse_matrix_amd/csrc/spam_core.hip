@@ -336,7 +336,7 @@ int spam_hip_copy_gbps(uint64_t bytes, int reps, double* gbps_out) {
   SPAM_TRY(a.alloc(n * 16));
   SPAM_TRY(b.alloc(n * 16));
   SPAM_HIP_TRY(hipMemsetAsync(a.p, 1, n * 16, s));
-  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256ull * 64);
+  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 65536);  // (tools/copy_bench.hip: the fastest of the variants tried)
   hipEvent_t e0, e1;
   SPAM_HIP_TRY(hipEventCreate(&e0));
   SPAM_HIP_TRY(hipEventCreate(&e1));

@@ -2,6 +2,10 @@
 // spam_csr/src/lib.rs:267-274, which the reference runs serially on the CPU twice per product,
 // mul_hash.rs:51,117).  Three launches: per-block sums, one block scanning the block sums, per-block
 // scan + offset.  HBM-bound: reads n*sizeof(In) twice, writes (n+1)*8 once.
+// Overflow (the reference panics on checked_add, lib.rs:270): the sums are u64 and cannot wrap for either use —
+// u32 inputs (entries per row of C, flags) over fewer than 2^32 elements stay below 2^64; the u64 input (per-row
+// partition costs) is admitted by spam_rows_to_parts* only when the total F, itself overflow-checked while it is
+// counted (spgemm_flops_kernel), is below 2^63.
 #include "spam_internal.hpp"
 
 namespace spam {

@@ -71,6 +71,16 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
+// the same sum through DPP moves (no LDS crossbar round trips); the total is returned in every lane
+__device__ __forceinline__ uint32_t wave_sum_dpp_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 // ---- L1: per-row intermediate-product count (mul_hash.rs:39-50) -------------------------------------
 // One wavefront per row; B.row_ptr gathers are the traffic.  total[0] += F, total[1] |= overflow.
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restr
       for (int i = 0; i < BM_WORDS / 1024; ++i) {
         const uint32_t v = bm[i * 1024 + threadIdx.x];
         if (v) bm[i * 1024 + threadIdx.x] = 0;
-        const uint32_t n = wave_sum_u32(__popc(v));
+        const uint32_t n = wave_sum_dpp_u32(__popc(v));
         if ((threadIdx.x & 63) == 0 && n) atomicAdd(&ccnt[(i * 1024 + threadIdx.x) >> (cw_shift - 5)], n);
       }
       __syncthreads();
@@ -2542,6 +2552,10 @@ static int rows_to_parts_impl(const spam_csr* a, const spam_csr* b, uint64_t npa
   if (row_flops_out) SPAM_HIP_TRY(hipMemcpyAsync(row_flops_out, flops.p, a->rows * 8, hipMemcpyDeviceToHost, s));
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (htot[1]) return set_error(SPAM_E_OVERFLOW, "intermediate-product count overflows usize (mul_hash.rs:47-48)");
+  // the scanned cost adds row_overhead per non-empty row to F: keep the u64 prefix sums of checked_inclusive_scan
+  // (lib.rs:267-274) from wrapping (rows < 2^32, so F < 2^63 leaves room for any sane overhead)
+  if (htot[0] >= (1ull << 63) || row_overhead >= (1ull << 30))
+    return set_error(SPAM_E_OVERFLOW, "partition cost would overflow the u64 prefix sums (lib.rs:270)");
   return SPAM_OK;
 }
 

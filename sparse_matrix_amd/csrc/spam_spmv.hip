@@ -1500,7 +1500,7 @@ template <class T>
 static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, hipStream_t s) {
   const uint32_t cols = (uint32_t)a->cols;
   const uint32_t rows = (uint32_t)a->rows;
-  sliced_build_tables_kernel<T><<<(std::max(cols, rows) + 255) / 256, 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
+  sliced_build_tables_kernel<T><<<(unsigned)(((uint64_t)std::max(cols, rows) + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
   SPAM_CHECK_LAUNCH();
   // (running the short rows beside the slab kernel on a second stream was measured 3 % slower than one after the other)
   SPAM_TRY(residual_run<T>(a, q, x, y, s));

@@ -81,6 +81,18 @@ def test_very_wide_b_several_bitmap_windows(spam, oracle):
     _exact_unsorted(spam, oracle, ma, mb)
 
 
+@pytest.mark.parametrize("cols", [20_000_000, 70_000_000])
+def test_very_wide_b_beyond_2_pow_24_columns(spam, oracle, cols):
+    """cols(B) > 2^24 with heavy rows (round 1 refused these: the heavy path kept its chunk list in LDS).  20 M columns =
+    2442 chunks of 8192; 70 M columns exceeds 8192 such chunks and switches to the 16384-column geometry; rows of C
+    with ~19 k entries spread over the whole width (most groups are span-limited), all three output orders."""
+    ma = synth.random_csr(5, 1000, 0.004 * 1000 / 1000, seed=51, signed=False)
+    mb = synth.random_csr(1000, cols, 5000 / cols, seed=52, signed=False)
+    C = _both(spam, oracle, ma, mb, F64_RTOL)
+    assert np.diff(C.offsets.astype(np.int64)).max() > 4096
+    _exact_unsorted(spam, oracle, ma, mb)
+
+
 def test_unsorted_b_heavy_rows_filter_path(spam, oracle):
     """Unsorted B cannot be pre-split; heavy rows then filter every product by chunk."""
     ma = synth.random_csr(8, 300, 0.6, seed=21, signed=False)
