@@ -59,8 +59,9 @@ typedef struct spam_spgemm_stats {
   uint64_t flops_f;                /* F = sum of intermediate products (row_nz before symbolic, mul_hash.rs:39-50) */
   uint64_t rows_sym_bin[8];        /* rows per symbolic bin (by F)   */
   uint64_t rows_num_bin[8];        /* rows per numeric bin (by nnz)  */
-  uint64_t heavy_items;            /* rows on the heavy (chunked LDS accumulator) numeric path */
-  uint64_t heavy_dense_groups, heavy_hash_groups; /* their column-chunk groups by accumulator kind */
+  uint64_t heavy_items;            /* rows on the heavy numeric path (more than 4096 entries of C) */
+  uint64_t heavy_dense_groups, heavy_hash_groups; /* their (row, column group) work items: rank-addressed accumulator /
+                                                   * (none since round 2: the per-group hash table is gone) */
   uint64_t heavy_dense_nnz, heavy_hash_nnz;       /* entries of C produced by each kind */
   float ms_flops, ms_symbolic, ms_alloc, ms_numeric, ms_total; /* device time, HIP events on the library stream */
 } spam_spgemm_stats;
@@ -173,7 +174,8 @@ int spam_spmv_sliced_info(const spam_csr* a, int* active, uint64_t* long_rows, u
  *                         Vec::with_capacity(nnz) exactly as mul_hash.rs:119 does.
  * spam_spgemm_numeric_* = mul_hash_numeric::<B1, B2> (:106-201); sort_rows is the const generic B2
  *                         (rows sorted by column).  With sort_rows = 0 each row is emitted in this
- *                         library's own table order: the same SET of (col, value) per row as the
+ *                         library's own order — rows of up to 4096 entries in the slot order of a table filled
+ *                         in parallel, longer rows in column order: the same SET of (col, value) per row as the
  *                         reference, not its linprobe slot order.  sort_rows = 2 (SPAM_ORDER_REFERENCE)
  *                         reproduces the reference's unsorted output exactly — linprobe slot order,
  *                         map.rs:59-63 (rows above 4096 entries build their table in HBM: a verification

@@ -2,14 +2,15 @@
 //
 // Reference counterpart: CsrMatrix::mul_hash (spam_csr/src/mul_hash.rs:13-201) with its linprobe
 // accumulator (linprobe/src/{lib,set,map}.rs):
-//   rows_to_threads  :38-64   -> spgemm_flops_kernel; partition rule in part_points_kernel (spam_rows_to_parts*)
+//   rows_to_threads  :38-64   -> spgemm_flops_kernel; partition rule in part_points_kernel (spam_rows_to_parts*,
+//                                spam_spgemm_rank_step)
 //   mul_hash_symbolic:66-103  -> sym_hash_kernel (rows of <= 512 products, several rows per workgroup),
 //                                sym_row_kernel (<= 4096, one row per workgroup), sym_heavy_kernel (bitmap windows)
 //   checked_inclusive_scan (lib.rs:267-274) -> scan_u32_to_u64
 //   mul_hash_numeric :106-201 -> num_hash_kernel / num_row_kernel (LDS linprobe map: u32 keys + T values, atomicCAS
-//                                claim + LDS atomic add) and num_heavy_kernel (per row: dense T accumulator over a
-//                                16384-column chunk, or one table shared by a run of sparser chunks, both in LDS)
-//   B2 (sort rows)   :164-175 -> sort_rows_kernel (bitonic in LDS); heavy rows sort inside num_heavy_kernel
+//                                claim + LDS atomic add) for rows of up to 4096 entries; beyond: heavy_groups_kernel
+//                                (work items) + num_heavy_kernel (rank-addressed LDS accumulator: bitmap + prefix popcount)
+//   B2 (sort rows)   :164-175 -> sort_rows_kernel (bitonic in LDS); heavy rows are produced in column order
 //   linprobe slot order (map.rs:59-63) -> ref_order_kernel / minpos_heavy_kernel + ref_order_long_kernel (sort_rows = 2)
 //
 // Where the CPU code gives each thread a contiguous flop-balanced row range (mul_hash.rs:52-62), the GPU bins rows
@@ -17,13 +18,12 @@
 // lanes per row (16 / 64 / 256 / 1024) and the LDS table size; the hash bins keep linprobe's hash (key * 107) &
 // (size - 1), its sentinel u32::MAX and its sizing max(16, 2 * next_pow2(n)).  Rows whose table would not fit LDS
 // take the "heavy" path: the column range is cut into chunks, B's sorted rows are pre-split at the chunk boundaries
-// (bpos) so a chunk range touches only its own products, and a row's chunks are accumulated group by group in LDS.
-// All one-row-per-workgroup kernels walk the products the same way: the B segments of up to SEG entries of A's row
-// are prefix-summed in LDS and each wavefront takes 64*U consecutive products per round (lane-contiguous loads).
-// Heavy rows are pulled from device-wide queues, heaviest first.  No MFMA: nothing here is a dense contraction.
+// (bpos) so a chunk range touches only its own products, a row's chunks are packed into groups that fit the LDS
+// accumulator, and every (row, group) becomes a work item of a device-wide queue ordered by column window (see the
+// comment above num_heavy_kernel).  No MFMA: nothing here is a dense contraction.
 //
-// Output order: sort_rows = 0 this library's table order (hash rows: slot order of a table filled in parallel;
-// heavy rows: chunk group by chunk group), 1 sorted by column (B2), 2 the reference's exact linprobe slot order.
+// Output order: sort_rows = 0 this library's own order (hash rows: slot order of a table filled in parallel; heavy
+// rows: column order), 1 sorted by column (B2), 2 the reference's exact linprobe slot order.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>

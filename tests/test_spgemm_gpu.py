@@ -196,6 +196,33 @@ def test_row_block_product_equals_slice(spam, oracle):
         assert_csr_parity((o, i, v), (wo, want[1][s:e], want[2][s:e]), True, F64_RTOL)
 
 
+def test_rank_step_entry_point(spam, oracle):
+    """spam_spgemm_rank_step (the per-rank sequence of the row-sharded multi-GPU product as ONE C call): for every rank of
+    a 3-rank and an 8-rank world the returned block is rows [row_lo, row_hi) of the full product, the ranges tile the
+    rows in order and equal the weighted partition (rows_to_threads on F + 2300 per non-empty row)."""
+    m = synth.rmat(11)
+    A, a = _mk(spam, m)
+    dev = A.device()
+    want = oracle.mul_hash(a, a, sort_rows=True)
+    for world in (3, 8):
+        offs = dev.balanced_row_blocks(dev, world, 2300)
+        nxt = 0
+        for rank in range(world):
+            C, st, (lo, hi) = dev.rank_step(dev, rank, world, 2300, sort_rows=True)
+            assert (lo, hi) == (offs[rank], offs[rank + 1]) and lo == nxt
+            nxt = hi
+            if hi == lo:
+                assert C is None
+                continue
+            o, i, v = C.download()
+            s, e = int(want[0][lo]), int(want[0][hi])
+            assert_csr_parity((o, i, v), (want[0][lo:hi + 1] - want[0][lo], want[1][s:e], want[2][s:e]), True, F64_RTOL)
+            assert st["nnz_c"] == e - s
+        assert nxt == m.rows
+    with pytest.raises(spam.SpamError):
+        dev.rank_step(dev, 3, 3)
+
+
 def test_full_size_row_sum_property(spam, oracle):
     """BASELINE configs[2] at full size (R-MAT scale 20: F = 2.09e10 products, nnz(C) = 9.7e9 > 2^32).
     (1) a check that needs no CPU product: (A*A)*x == A*(A*x) row by row for a RANDOM positive x (a permuted or
