@@ -874,7 +874,11 @@ constexpr uint32_t LONG_SEG = 64;    // segments of at least this many products 
 #ifndef SPAM_PIECE_U
 #define SPAM_PIECE_U 8
 #endif
-constexpr int PIECE_U = SPAM_PIECE_U;  // pieces per round of the long-segment path (two rounds of loads in flight)
+constexpr int PIECE_U = SPAM_PIECE_U;  // pieces per round of the long-segment path in pass 2 (column + value loads)
+#ifndef SPAM_PIECE_U1
+#define SPAM_PIECE_U1 8
+#endif
+constexpr int PIECE_U1 = SPAM_PIECE_U1;  // ... and in pass 1 (column loads only)
 
 struct RankWord {  // one bitmap word of the group's column span
   uint32_t prefix;  // entries of the group in lower words (valid after the prefix step)
@@ -935,12 +939,13 @@ __device__ __forceinline__ void long_pieces(uint64_t lmask, uint32_t lo, uint32_
       p = deal > 1 ? (wave + deal - (sidx % deal)) % deal : 0u;
     }
   };
+  constexpr int PU = PASS == 1 ? PIECE_U1 : PIECE_U;
   bool more = next_piece();
   while (more) {
-    uint32_t cols[PIECE_U];
-    T prods[PIECE_U], sa[PIECE_U];  // (sa: one scalar per piece)
+    uint32_t cols[PU];
+    T prods[PU], sa[PU];  // (sa: one scalar per piece)
 #pragma unroll
-    for (int j = 0; j < PIECE_U; ++j) {
+    for (int j = 0; j < PU; ++j) {
       cols[j] = EMPTY_KEY;
       prods[j] = T(0), sa[j] = T(0);
       if (more) {  // (uniform)
@@ -957,9 +962,9 @@ __device__ __forceinline__ void long_pieces(uint64_t lmask, uint32_t lo, uint32_
     }
     if (PASS == 2) {  // only now: a multiply right behind its load would make every piece wait for its own round trip
 #pragma unroll
-      for (int j = 0; j < PIECE_U; ++j) prods[j] = sa[j] * prods[j];  // t * t1 (mul_hash.rs:154)
+      for (int j = 0; j < PU; ++j) prods[j] = sa[j] * prods[j];  // t * t1 (mul_hash.rs:154)
     }
-    accumulate_round<T, PASS, PIECE_U>(cols, prods, c0, cspan, words, vals);
+    accumulate_round<T, PASS, PU>(cols, prods, c0, cspan, words, vals);
   }
 }
 
