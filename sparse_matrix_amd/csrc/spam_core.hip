@@ -296,7 +296,7 @@ using namespace spam;
 
 extern "C" {
 
-int spam_version(void) { return 1000; }
+int spam_version(void) { return 1001; }  // 1001: + spmv_prepare, values_changed, rank_step, i64 entry points, copy_gbps
 
 const char* spam_last_error(void) { return g_err.c_str(); }
 

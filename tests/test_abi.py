@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in spam_hip.h but missing from libspam_hip.so"
     assert sorted(_lib.SYMBOLS) == names, "python binding table and header disagree"
-    assert lib.spam_version() == 1000
+    assert lib.spam_version() == 1001
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
