@@ -897,74 +897,91 @@ __device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[U], cons
     }
   } else {
     RankWord w[U];
+    uint32_t slot[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const uint32_t rel = cols[j] - c0;
       w[j].prefix = 0, w[j].bits = 0;
       if (cols[j] != EMPTY_KEY && rel < cspan) w[j] = words[rel >> 5];  // all reads in flight together
     }
+    // the ranks first, unconditionally and in straight-line code, the adds afterwards: an add issued between two rank
+    // computations makes the next one's wait for its word (lgkmcnt) wait for that add's round trip as well
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      slot[j] = w[j].prefix + __popc(w[j].bits & ((1u << ((cols[j] - c0) & 31)) - 1u));
+      asm volatile("" : "+v"(slot[j]));  // (keeps the compiler from sinking the rank into the guarded add below)
+    }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const uint32_t rel = cols[j] - c0;
-      if (cols[j] != EMPTY_KEY && rel < cspan)
-        lds_add(&vals[w[j].prefix + __popc(w[j].bits & ((1u << (rel & 31)) - 1u))], prods[j]);
+      if (cols[j] != EMPTY_KEY && rel < cspan) lds_add(&vals[slot[j]], prods[j]);
     }
   }
 }
 
-// Long segments: 64-product pieces whose parameters are scalars (v_readlane of the owning lane's registers): a piece
-// is one coalesced load of columns (and one of values in pass 2) at a scalar base + lane, no segment search, no
-// shuffles.  `deal` = NW for the shared entries every wavefront holds (piece p of segment s goes to wavefront
-// (s + p) mod NW, so a hub's products spread evenly over the workgroup) and 1 for entries this wavefront owns alone.
-// WAVE_U pieces are gathered per round so that their loads are in flight together.
+// Long segments: 64-product pieces.  `deal` = NW for the shared entries every wavefront holds (piece p of segment s goes
+// to wavefront (s + p) mod NW, so a hub's products spread evenly over the workgroup) and 1 for entries this wavefront
+// owns alone.  The wavefront's pieces are numbered through (lane s contributes cnt[s] of them, prefix-summed with DPP
+// moves) and lane t builds the descriptor of piece base + t: its segment by the same lockstep bisection the short
+// segments use — once per 64 pieces —, then position, length and A's value by ds_bpermute.  A round reads PIECE_U
+// descriptors back as scalars (v_readlane at a uniform index): a piece is one coalesced load of columns (and one of
+// values in pass 2) at a scalar base + lane, and all loads of the round are in flight together.  (A scalar iterator
+// walking the segments piece by piece cost more issue slots than the products: ~60 scalar instructions and a dozen
+// branches per piece.)
 template <class T, int PASS>
-__device__ __forceinline__ void long_pieces(uint64_t lmask, uint32_t lo, uint32_t len, T av, uint32_t deal, uint32_t wave,
+__device__ __forceinline__ void long_pieces(uint32_t lo, uint32_t len, T av, uint32_t deal, uint32_t wave,
                                             const uint32_t* __restrict__ b_col, const T* __restrict__ b_val, uint32_t c0,
                                             uint32_t cspan, RankWord* words, T* vals) {
   const uint32_t lane = threadIdx.x & 63;
-  // scalar piece iterator
-  uint64_t m = lmask;
-  uint32_t s_lo = 0, s_len = 0, p = 0, np = 0;
-  T s_a = T(0);
-  auto next_piece = [&]() -> bool {  // advances (s_lo, s_len, s_a, p) to this wavefront's next piece; false when done
-    for (;;) {
-      if (p < np) return true;
-      if (!m) return false;
-      const uint32_t sidx = (uint32_t)__builtin_ctzll(m);
-      m &= m - 1;
-      s_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)sidx);
-      s_len = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)sidx);
-      if (PASS == 2) s_a = readlane_val(av, sidx);
-      np = (s_len + 63) >> 6;
-      p = deal > 1 ? (wave + deal - (sidx % deal)) % deal : 0u;
-    }
-  };
+  const uint32_t np = len >= LONG_SEG ? (len + 63) >> 6 : 0u;                       // pieces of this lane's segment
+  const uint32_t p0 = deal > 1 ? (wave + deal - (lane % deal)) % deal : 0u;         // this wavefront's first one
+  const uint32_t cnt = p0 < np ? (np - 1 - p0) / deal + 1 : 0u;                     // ... and how many: p0, p0 + deal, ...
+  const uint32_t inc = wave_incl_scan_u32(cnt);
+  const uint32_t st = inc - cnt;
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
   constexpr int PU = PASS == 1 ? PIECE_U1 : PIECE_U;
-  bool more = next_piece();
-  while (more) {
-    uint32_t cols[PU];
-    T prods[PU], sa[PU];  // (sa: one scalar per piece)
+  for (uint32_t base = 0; base < total; base += 64) {
+    const uint32_t nb = total - base < 64 ? total - base : 64;  // descriptors of this batch (uniform)
+    const uint32_t g = base + lane;
+    // the segment of piece g: the last lane whose start is <= g (st is non-decreasing; lanes without pieces share
+    // their successor's start)
+    const uint32_t w1 = base + nb - 1;
+    uint32_t slo = (uint32_t)__popcll(__ballot(st <= base)) - 1u, shi = (uint32_t)__popcll(__ballot(st <= w1)) - 1u;
+    for (uint32_t span = shi - slo; span != 0; span >>= 1) {  // uniform trip count
+      const uint32_t mid = (slo + shi + 1) >> 1;
+      if (shfl_u32(st, mid) <= g)
+        slo = mid;
+      else
+        shi = mid - 1;
+    }
+    const uint32_t k = g - shfl_u32(st, slo);
+    const uint32_t pp = (shfl_u32(p0, slo) + k * deal) * 64;  // first product of the piece inside its segment
+    uint32_t q0 = shfl_u32(lo, slo) + pp;
+    uint32_t n = shfl_u32(len, slo) - pp;
+    T a = PASS == 2 ? shfl_val(av, slo) : T(0);
+    if (lane >= nb) n = 0;
+    for (uint32_t r = 0; r < nb; r += PU) {  // (r + j <= 63: nb <= 64 and PU divides 64)
+      uint32_t cols[PU];
+      T prods[PU], sa[PU];
 #pragma unroll
-    for (int j = 0; j < PU; ++j) {
-      cols[j] = EMPTY_KEY;
-      prods[j] = T(0), sa[j] = T(0);
-      if (more) {  // (uniform)
-        const uint32_t n = s_len - p * 64;  // products left in the segment from this piece on
-        if (lane < n) {
-          const uint64_t q = (uint64_t)s_lo + p * 64 + lane;
+      for (int j = 0; j < PU; ++j) {
+        const uint32_t qj = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)(r + j));
+        const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)(r + j));
+        sa[j] = PASS == 2 ? readlane_val(a, r + j) : T(0);
+        cols[j] = EMPTY_KEY;
+        prods[j] = T(0);
+        if (lane < nj) {
+          const uint64_t q = (uint64_t)qj + lane;
           cols[j] = b_col[q];
           if (PASS == 2) prods[j] = b_val[q];
         }
-        sa[j] = s_a;
-        p += deal;
-        more = next_piece();
       }
-    }
-    if (PASS == 2) {  // only now: a multiply right behind its load would make every piece wait for its own round trip
+      if (PASS == 2) {  // only now: a multiply right behind its load would make every piece wait for its own round trip
 #pragma unroll
-      for (int j = 0; j < PU; ++j) prods[j] = sa[j] * prods[j];  // t * t1 (mul_hash.rs:154)
+        for (int j = 0; j < PU; ++j) prods[j] = sa[j] * prods[j];  // t * t1 (mul_hash.rs:154)
+      }
+      accumulate_round<T, PASS, PU>(cols, prods, c0, cspan, words, vals);
     }
-    accumulate_round<T, PASS, PU>(cols, prods, c0, cspan, words, vals);
   }
 }
 
@@ -982,7 +999,7 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
                                               uint32_t cspan, RankWord* words, T* vals) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t lmask = __ballot(len >= LONG_SEG);
-  if (lmask) long_pieces<T, PASS>(lmask, lo, len, av, shared ? nw : 1u, wave, b_col, b_val, c0, cspan, words, vals);
+  if (lmask) long_pieces<T, PASS>(lo, len, av, shared ? nw : 1u, wave, b_col, b_val, c0, cspan, words, vals);
   if (len >= LONG_SEG || (shared && (lane % nw) != wave)) len = 0;
   const uint32_t inc = wave_incl_scan_u32(len);
   const uint32_t st = inc - len;                         // first product index of this lane's segment
@@ -1373,6 +1390,10 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
       t0 = t1;
     }
     // ---- drain: the values are the row piece in column order; the columns are expanded from the bitmap -----------
+    // vmcnt(0) here, where every load in flight (the prefetches for the coming items) has long landed: without it the
+    // compiler, which cannot tell, puts that wait inside the store loops below, where it waits for the loop's own
+    // stores to be acknowledged, once per trip.  (simm16: vmcnt 0, expcnt 7, lgkmcnt 15)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     const uint64_t out = it_c.out;
     const uint32_t cnt = it_c.cnt;
     for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
