@@ -870,7 +870,10 @@ __device__ __forceinline__ float readlane_val(float v, uint32_t src_lane) {
 #define SPAM_WAVE_U 4
 #endif
 constexpr int WAVE_U = SPAM_WAVE_U;  // products per lane and round: that many independent (col, val) loads in flight per lane
-constexpr uint32_t LONG_SEG = 64;    // segments of at least this many products are cut into scalar pieces
+#ifndef SPAM_LONG_SEG
+#define SPAM_LONG_SEG 64
+#endif
+constexpr uint32_t LONG_SEG = SPAM_LONG_SEG;  // segments of at least this many products are cut into 64-product pieces
 #ifndef SPAM_PIECE_U
 #define SPAM_PIECE_U 8
 #endif
@@ -879,6 +882,10 @@ constexpr int PIECE_U = SPAM_PIECE_U;  // pieces per round of the long-segment p
 #define SPAM_PIECE_U1 8
 #endif
 constexpr int PIECE_U1 = SPAM_PIECE_U1;  // ... and in pass 1 (column loads only)
+#ifndef SPAM_FLAT_EARLY
+#define SPAM_FLAT_EARLY 1
+#endif
+constexpr bool FLAT_EARLY = SPAM_FLAT_EARLY != 0;  // pass 1: first short-segment round in flight during the piece rounds
 
 struct RankWord {  // one bitmap word of the group's column span
   uint32_t prefix;  // entries of the group in lower words (valid after the prefix step)
@@ -960,14 +967,15 @@ __device__ __forceinline__ void long_pieces(uint32_t lo, uint32_t len, T av, uin
     uint32_t n = shfl_u32(len, slo) - pp;
     T a = PASS == 2 ? shfl_val(av, slo) : T(0);
     if (lane >= nb) n = 0;
-    for (uint32_t r = 0; r < nb; r += PU) {  // (r + j <= 63: nb <= 64 and PU divides 64)
+    for (uint32_t r = 0; r < nb; r += PU) {
       uint32_t cols[PU];
       T prods[PU], sa[PU];
 #pragma unroll
       for (int j = 0; j < PU; ++j) {
-        const uint32_t qj = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)(r + j));
-        const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)(r + j));
-        sa[j] = PASS == 2 ? readlane_val(a, r + j) : T(0);
+        const uint32_t dl = (r + j) & 63;  // (lanes >= nb hold n = 0; the index only wraps when 64 is no multiple of PU)
+        const uint32_t qj = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)dl);
+        const uint32_t nj = (64 % PU == 0 || r + j < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)n, (int)dl) : 0u;
+        sa[j] = PASS == 2 ? readlane_val(a, dl) : T(0);
         cols[j] = EMPTY_KEY;
         prods[j] = T(0);
         if (lane < nj) {
@@ -999,16 +1007,16 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
                                               uint32_t cspan, RankWord* words, T* vals) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t lmask = __ballot(len >= LONG_SEG);
-  if (lmask) long_pieces<T, PASS>(lo, len, av, shared ? nw : 1u, wave, b_col, b_val, c0, cspan, words, vals);
-  if (len >= LONG_SEG || (shared && (lane % nw) != wave)) len = 0;
-  const uint32_t inc = wave_incl_scan_u32(len);
-  const uint32_t st = inc - len;                         // first product index of this lane's segment
+  const uint32_t slen = (len >= LONG_SEG || (shared && (lane % nw) != wave)) ? 0u : len;  // this lane's short segment
+  const uint32_t inc = wave_incl_scan_u32(slen);
+  const uint32_t st = inc - slen;                        // first product index of this lane's segment
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
   const uint32_t off = lo - st;                          // q = off[s] + idx for a product index idx of segment s
-  for (uint32_t base = 0; base < total; base += 64 * WAVE_U) {
+  // one round of the short segments, in two halves: the segment search and the loads ...
+  auto issue = [&](uint32_t base, uint32_t (&slo)[WAVE_U], uint32_t (&cols)[WAVE_U], T (&bv)[WAVE_U]) {
     // st is non-decreasing over the lanes: the lanes with st <= w form a prefix whose last member is the segment
     // holding product w (empty segments share their successor's start and are skipped by taking the last)
-    uint32_t slo[WAVE_U], shi[WAVE_U];
+    uint32_t shi[WAVE_U];
     uint32_t maxspan = 0;
 #pragma unroll
     for (int j = 0; j < WAVE_U; ++j) {
@@ -1038,8 +1046,7 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
           shi[j] = mid[j] - 1;
       }
     }
-    uint32_t cols[WAVE_U], qq[WAVE_U];
-    T bv[WAVE_U], aa[WAVE_U], prods[WAVE_U];
+    uint32_t qq[WAVE_U];
 #pragma unroll
     for (int j = 0; j < WAVE_U; ++j) qq[j] = shfl_u32(off, slo[j]);
 #pragma unroll
@@ -1052,11 +1059,31 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
         if (PASS == 2) bv[j] = b_val[qq[j] + idx];
       }
     }
+  };
+  // ... and the accumulation
+  auto finish = [&](const uint32_t (&slo)[WAVE_U], const uint32_t (&cols)[WAVE_U], const T (&bv)[WAVE_U]) {
+    T aa[WAVE_U], prods[WAVE_U];
 #pragma unroll
     for (int j = 0; j < WAVE_U; ++j) aa[j] = PASS == 2 ? shfl_val(av, slo[j]) : T(0);
 #pragma unroll
     for (int j = 0; j < WAVE_U; ++j) prods[j] = aa[j] * bv[j];  // t * t1 (mul_hash.rs:154)
     accumulate_round<T, PASS, WAVE_U>(cols, prods, c0, cspan, words, vals);
+  };
+  // The first round of the short segments is issued BEFORE the pieces of the long ones and accumulated after them: its
+  // round trip to memory overlaps theirs (a wavefront has ~3 piece rounds and ~1.7 short rounds per pass, every one a
+  // full memory latency).  Pass 1 only: in pass 2 the values would have to be held as well, and there are no
+  // registers left for them.
+  constexpr bool EARLY = FLAT_EARLY && PASS == 1;
+  uint32_t slo0[WAVE_U], cols0[WAVE_U];
+  T bv0[WAVE_U];
+  if (EARLY && total) issue(0, slo0, cols0, bv0);
+  if (lmask) long_pieces<T, PASS>(lo, len, av, shared ? nw : 1u, wave, b_col, b_val, c0, cspan, words, vals);
+  if (EARLY && total) finish(slo0, cols0, bv0);
+  for (uint32_t base = EARLY ? 64 * WAVE_U : 0; base < total; base += 64 * WAVE_U) {
+    uint32_t slo[WAVE_U], cols[WAVE_U];
+    T bv[WAVE_U];
+    issue(base, slo, cols, bv);
+    finish(slo, cols, bv);
   }
 }
 
