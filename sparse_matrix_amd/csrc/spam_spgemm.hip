@@ -287,13 +287,12 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void sym_hash_kernel(
   if (valid && gl == 0) row_nnz[row] = cnt[g];  // *row_nz = hs.len() (mul_hash.rs:95)
 }
 
-// ---- flattened product space for the heavy kernels ---------------------------------------------------
+// ---- flattened product space of the one-row-per-workgroup kernels -------------------------------------
 // A batch of up to SEG entries k of A's row gives SEG segments [lo_s, lo_s + len_s) of B's arrays.  Their
 // lengths are prefix-summed into LDS (seg_start) and the workgroup then walks the concatenated product
-// index space: thread t takes HEAVY_U consecutive products per round (one binary search, then a forward
-// walk over segment boundaries), so lanes stay busy whatever the mix of short and long B rows, and each
-// lane has HEAVY_U independent loads in flight.
-constexpr int HEAVY_U = 8;
+// index space: every thread takes several products per round (one binary search, then a forward walk over
+// segment boundaries), so lanes stay busy whatever the mix of short and long B rows, and each lane has that
+// many independent loads in flight.
 
 // exclusive prefix + block total in every thread (two barriers, none needed afterwards to read the total)
 template <int TPB>
@@ -548,108 +547,6 @@ __global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ 
   }
 }
 
-// Symbolic pass for heavy rows: one workgroup per row, a 2^20-column bitmap window in LDS (LDS atomic OR),
-// then a popcount per numeric chunk.  The row's k list stays in LDS across windows when it fits.
-constexpr int BM_WORDS = 32768;                  // 128 KB bitmap = 2^20 columns = 64 numeric chunks per window
-constexpr int BM_CHUNKS_MAX = (BM_WORDS * 32) >> CW_SHIFT_256;  // 256 chunks per window at most
-constexpr int BM_SHIFT = 20;
-
-template <bool USE_BPOS>
-__global__ __launch_bounds__(1024) void sym_heavy_kernel(const uint64_t* __restrict__ a_rp,
-                                                        const uint32_t* __restrict__ a_col,
-                                                        const uint64_t* __restrict__ b_rp,
-                                                        const uint32_t* __restrict__ b_col,
-                                                        const uint32_t* __restrict__ bpos, uint32_t rows_b,
-                                                        const uint32_t* __restrict__ heavy_rows /* heaviest first */,
-                                                        uint32_t n_heavy, const uint32_t* __restrict__ hrow_of_row,
-                                                        uint32_t nchunks, int cw_shift, uint32_t* __restrict__ hcnt,
-                                                        uint32_t* __restrict__ queue) {
-  constexpr int SEG = 1024;
-  const uint32_t BM_CHUNKS = (BM_WORDS * 32u) >> cw_shift;  // numeric chunks per bitmap window
-  __shared__ uint32_t item_s;
-  __shared__ uint32_t bm[BM_WORDS];
-  __shared__ uint32_t seg_start[SEG + 1];
-  __shared__ uint32_t seg_lo[SEG];
-  __shared__ uint32_t klist[SEG];
-  __shared__ uint32_t wsum[17];
-  __shared__ uint32_t ccnt[BM_CHUNKS_MAX];
-  for (int i = threadIdx.x; i < BM_WORDS; i += 1024) bm[i] = 0;
-  if (threadIdx.x < BM_CHUNKS) ccnt[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t nwin = (nchunks + BM_CHUNKS - 1) / BM_CHUNKS;
-  for (;;) {  // rows from a device-wide queue (their cost varies by three orders of magnitude)
-    __syncthreads();
-    if (threadIdx.x == 0) item_s = atomicAdd(queue, 1u);
-    __syncthreads();
-    if (item_s >= n_heavy) break;
-    const uint32_t row = heavy_rows[item_s];
-    const uint32_t hrow = hrow_of_row[row];
-    const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
-    const bool cached = (pe - ps) <= SEG;
-    if (cached && ps + threadIdx.x < pe) klist[threadIdx.x] = a_col[ps + threadIdx.x];
-    __syncthreads();
-    for (uint32_t win = 0; win < nwin; ++win) {
-      const uint32_t j0 = win * BM_CHUNKS, j1 = (j0 + BM_CHUNKS < nchunks) ? j0 + BM_CHUNKS : nchunks;
-      const uint32_t c0 = win << BM_SHIFT;
-      for (uint64_t pb = ps; pb < pe; pb += SEG) {
-        const uint64_t p = pb + threadIdx.x;
-        uint32_t lo = 0, len = 0;
-        if (p < pe) {
-          const uint32_t k = cached ? klist[threadIdx.x] : a_col[p];
-          if (USE_BPOS) {
-            lo = bpos[(uint64_t)j0 * rows_b + k];
-            len = bpos[(uint64_t)j1 * rows_b + k] - lo;
-          } else {
-            lo = (uint32_t)b_rp[k];
-            len = (uint32_t)b_rp[k + 1] - lo;
-          }
-        }
-        uint32_t total;
-        const uint32_t st = block_excl_scan_tot<1024>(len, wsum, total);
-        seg_start[threadIdx.x] = st;
-        seg_lo[threadIdx.x] = lo - st;  // q = seg_lo[s] + idx for a product index idx of segment s
-        if (threadIdx.x == 0) seg_start[SEG] = total;
-        __syncthreads();
-        // each wavefront takes 64*HEAVY_U consecutive products per round, lane-contiguous inside every load
-        for (uint32_t wb = (threadIdx.x >> 6) * (64 * HEAVY_U); wb < total; wb += 1024 * HEAVY_U) {
-          const uint32_t idx0 = wb + (threadIdx.x & 63);
-          uint32_t sg = seg_find(seg_start, SEG, idx0 < total ? idx0 : total - 1);
-          uint32_t cols[HEAVY_U];
-#pragma unroll
-          for (int j = 0; j < HEAVY_U; ++j) {
-            const uint32_t idx = idx0 + j * 64;
-            cols[j] = 0xFFFFFFFFu;
-            if (idx < total) {
-              sg = seg_advance(seg_start, SEG, sg, idx);
-              cols[j] = b_col[seg_lo[sg] + idx];
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < HEAVY_U; ++j) {
-            const uint32_t c = cols[j] - c0;
-            if (cols[j] != 0xFFFFFFFFu && c < (1u << BM_SHIFT)) atomicOr(&bm[c >> 5], 1u << (c & 31));
-          }
-        }
-        __syncthreads();
-      }
-      // popcount per numeric chunk (512 words each); the bitmap is reset on the way
-#pragma unroll 4
-      for (int i = 0; i < BM_WORDS / 1024; ++i) {
-        const uint32_t v = bm[i * 1024 + threadIdx.x];
-        if (v) bm[i * 1024 + threadIdx.x] = 0;
-        const uint32_t n = wave_sum_dpp_u32(__popc(v));
-        if ((threadIdx.x & 63) == 0 && n) atomicAdd(&ccnt[(i * 1024 + threadIdx.x) >> (cw_shift - 5)], n);
-      }
-      __syncthreads();
-      if (threadIdx.x < BM_CHUNKS) {
-        if (j0 + threadIdx.x < j1) hcnt[(uint64_t)hrow * nchunks + j0 + threadIdx.x] = ccnt[threadIdx.x];
-        ccnt[threadIdx.x] = 0;
-      }
-      __syncthreads();
-    }
-  }
-}
-
 // per heavy row: hoff = exclusive prefix of hcnt over chunks, row_nnz = total.  One wavefront per row.
 __global__ __launch_bounds__(256) void heavy_finalize_kernel(const uint32_t* __restrict__ heavy_rows, uint32_t n_heavy,
                                                             uint32_t nchunks, const uint32_t* __restrict__ hcnt,
@@ -892,11 +789,18 @@ struct RankWord {  // one bitmap word of the group's column span
   uint32_t bits;
 };
 
-// One round of WAVE_U products per lane.  PASS 1: mark the columns; PASS 2: add the products at their rank.
+// One round of WAVE_U products per lane.  PASS 0 (symbolic) / 1: mark the columns; PASS 2: add the products at their rank.
 template <class T, int PASS, int U>
 __device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[U], const T (&prods)[U], uint32_t c0,
                                                  uint32_t cspan, RankWord* words, T* vals) {
-  if (PASS == 1) {
+  if (PASS == 0) {  // symbolic phase: `words` is a plain bitmap, one bit per column of the window
+    uint32_t* bm = reinterpret_cast<uint32_t*>(words);
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t rel = cols[j] - c0;
+      if (cols[j] != EMPTY_KEY && rel < cspan) atomicOr(&bm[rel >> 5], 1u << (rel & 31));
+    }
+  } else if (PASS == 1) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const uint32_t rel = cols[j] - c0;
@@ -946,7 +850,7 @@ __device__ __forceinline__ void long_pieces(uint32_t lo, uint32_t len, T av, uin
   const uint32_t inc = wave_incl_scan_u32(cnt);
   const uint32_t st = inc - cnt;
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-  constexpr int PU = PASS == 1 ? PIECE_U1 : PIECE_U;
+  constexpr int PU = PASS <= 1 ? PIECE_U1 : PIECE_U;
   for (uint32_t base = 0; base < total; base += 64) {
     const uint32_t nb = total - base < 64 ? total - base : 64;  // descriptors of this batch (uniform)
     const uint32_t g = base + lane;
@@ -1073,7 +977,7 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
   // round trip to memory overlaps theirs (a wavefront has ~3 piece rounds and ~1.7 short rounds per pass, every one a
   // full memory latency).  Pass 1 only: in pass 2 the values would have to be held as well, and there are no
   // registers left for them.
-  constexpr bool EARLY = FLAT_EARLY && PASS == 1;
+  constexpr bool EARLY = FLAT_EARLY && PASS <= 1;
   uint32_t slo0[WAVE_U], cols0[WAVE_U];
   T bv0[WAVE_U];
   if (EARLY && total) issue(0, slo0, cols0, bv0);
@@ -1088,6 +992,184 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
 }
 
 constexpr uint32_t ITEM_RUN = 8;  // queue positions a workgroup claims per atomic
+
+// [lo, lo + len): the entries of B's row k with columns in the chunks [j0, j1) (the whole row without the pre-split)
+template <bool USE_BPOS>
+__device__ __forceinline__ void b_range(const uint32_t* __restrict__ bpos, const uint64_t* __restrict__ b_rp, uint32_t rows_b,
+                                        uint32_t j0, uint32_t j1, uint32_t k, uint32_t& lo, uint32_t& len) {
+  lo = 0, len = 0;
+  if (k != 0xFFFFFFFFu) {
+    if (USE_BPOS) {
+      lo = bpos[(uint64_t)j0 * rows_b + k];
+      len = bpos[(uint64_t)j1 * rows_b + k] - lo;
+    } else {
+      lo = (uint32_t)b_rp[k];
+      len = (uint32_t)b_rp[k + 1] - lo;
+    }
+  }
+}
+
+// Rows of A longer than 64 + 64 * NW entries: after the shared head, wavefront w takes the 64-entry batches w, w + NW,
+// ...; while batch i is multiplied the B-split lookups of batch i + 1 and the entries of batch i + 2 are in flight.
+template <class T, int PASS, bool USE_BPOS, int NW>
+__device__ __forceinline__ void streamed_products(const uint32_t* __restrict__ a_col, const T* __restrict__ a_val,
+                                                  uint64_t a_start, uint32_t n_a, uint32_t j0, uint32_t j1, uint32_t wave,
+                                                  const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
+                                                  const T* __restrict__ b_val, const uint32_t* __restrict__ bpos,
+                                                  uint32_t rows_b, uint32_t c0, uint32_t cspan, RankWord* words, T* vals) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t ps = a_start + 64, pe = a_start + n_a;
+  const uint64_t nb = ((uint64_t)n_a - 64 + 63) >> 6;
+  auto s_entry = [&](uint64_t bb, uint32_t& k, T& a) {
+    const uint64_t p = ps + (bb << 6) + lane;
+    k = 0xFFFFFFFFu, a = T(0);
+    if (bb < nb && p < pe) {
+      k = a_col[p];
+      if (PASS == 2) a = a_val[p];
+    }
+  };
+  uint32_t k1, k2, lo1, len1;
+  T a1, a2;
+  s_entry(wave, k1, a1);
+  s_entry(wave + NW, k2, a2);
+  b_range<USE_BPOS>(bpos, b_rp, rows_b, j0, j1, k1, lo1, len1);
+  for (uint64_t b = wave; b < nb; b += NW) {
+    const uint32_t lo_b = lo1, len_b = len1;
+    const T a_b = a1;
+    b_range<USE_BPOS>(bpos, b_rp, rows_b, j0, j1, k2, lo1, len1);
+    a1 = a2;
+    s_entry(b + 2 * NW, k2, a2);
+    wave_products<T, PASS>(lo_b, len_b, a_b, false, NW, wave, b_col, b_val, c0, cspan, words, vals);
+  }
+}
+
+// ---- symbolic phase of the heavy rows (mul_hash.rs:66-103 for rows with more than 4096 intermediate products) ----------
+// One workgroup per (row, column window): the window's columns are a bitmap in LDS (32 words per thread: 2^20 columns
+// with 1024 threads), the products are streamed exactly as in the numeric phase below — per-wavefront, shared head of
+// 64 entries dealt piecewise, owned entries, streamed batches — and marked with LDS atomic ORs; then every wavefront
+// counts the bits of its chunks (hcnt[heavy row][chunk], what the group builder packs by) and clears them.  Items come
+// from a device-wide queue in runs of ITEM_RUN, heaviest rows first; descriptors are read three items ahead, A's
+// entries two, the B-split lookups one, so a workgroup never waits for the chain queue -> row -> entries -> ranges.
+struct SymItem {     // 16 bytes, read with scalar loads
+  uint64_t a_start;  // first entry of A's row
+  uint32_t n_a;      // entries of A's row
+  uint32_t hrow;     // index of the row among the heavy rows
+};
+
+__global__ __launch_bounds__(256) void sym_items_kernel(const uint32_t* __restrict__ order, uint32_t n,
+                                                       const uint64_t* __restrict__ a_rp,
+                                                       const uint32_t* __restrict__ hrow_of_row, SymItem* __restrict__ items) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t row = order[i];
+  SymItem it;
+  it.a_start = a_rp[row], it.n_a = (uint32_t)(a_rp[row + 1] - a_rp[row]), it.hrow = hrow_of_row[row];
+  items[i] = it;
+}
+
+template <bool USE_BPOS, int TPB>
+__global__ __launch_bounds__(TPB) void sym_heavy_kernel(const uint32_t* __restrict__ a_col, const uint64_t* __restrict__ b_rp,
+                                                       const uint32_t* __restrict__ b_col, const uint32_t* __restrict__ bpos,
+                                                       uint32_t rows_b, const SymItem* __restrict__ items, uint32_t n_rows,
+                                                       uint32_t nwin, uint32_t nchunks, int cw_shift,
+                                                       uint32_t* __restrict__ hcnt, uint32_t* __restrict__ queue) {
+  constexpr int NW = TPB / 64;
+  constexpr uint32_t BM_WORDS = TPB * 32;                       // 128 KB at 1024 threads
+  constexpr uint32_t WIN_SHIFT = TPB == 1024 ? 20 : TPB == 512 ? 19 : 18;
+  static_assert(BM_WORDS * 32u == (1u << WIN_SHIFT), "window = 1024 columns per thread");
+  __shared__ __attribute__((aligned(16))) uint32_t bm[BM_WORDS];
+  __shared__ uint32_t run_s;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t n_items = n_rows * nwin;                       // (the host checks that this fits 32 bits)
+  const uint32_t ch_per_win = (1u << WIN_SHIFT) >> cw_shift;    // numeric chunks per window
+  const uint32_t cwords = (1u << cw_shift) >> 5;                // bitmap words per chunk
+  for (int i = threadIdx.x; i < (int)(BM_WORDS / 4); i += TPB) ((u32x4*)bm)[i] = (u32x4)(0u);
+  if (threadIdx.x == 0) run_s = atomicAdd(queue, ITEM_RUN);
+  __syncthreads();
+  uint32_t run_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_s), run_next = 0xFFFFFFFFu, pos = 0;
+  __syncthreads();
+  struct Cur {
+    uint64_t a_start;
+    uint32_t n_a, hrow, win, live;
+  };
+  auto item_index = [&](uint32_t ahead) -> uint32_t {  // queue position of the item `ahead` steps after the current one
+    const uint32_t q = pos + ahead;
+    if (q < ITEM_RUN) return run_base < n_items ? run_base + q : 0xFFFFFFFFu;
+    return run_next < n_items ? run_next + (q - ITEM_RUN) : 0xFFFFFFFFu;  // (ahead <= 3: the next run is known from pos 1 on)
+  };
+  auto load_item = [&](uint32_t idx, Cur& it) {
+    it.a_start = 0, it.n_a = 0, it.hrow = 0, it.win = 0, it.live = 0;
+    if (idx < n_items) {
+      const uint32_t r = nwin == 1 ? idx : idx / nwin;
+      const SymItem si = items[r];  // uniform address: scalar loads
+      it.a_start = si.a_start, it.n_a = si.n_a, it.hrow = si.hrow, it.win = idx - r * nwin, it.live = 1;
+    }
+  };
+  auto fetch_entry = [&](const Cur& it, uint32_t& ks, uint32_t& ko) {
+    ks = 0xFFFFFFFFu, ko = 0xFFFFFFFFu;
+    if (lane < it.n_a) ks = a_col[it.a_start + lane];
+    const uint32_t e = 64 + lane * NW + wave;
+    if (it.n_a <= (uint32_t)(64 + TPB) && e < it.n_a) ko = a_col[it.a_start + e];
+  };
+  auto fetch_range = [&](const Cur& it, uint32_t k, uint32_t& lo, uint32_t& len) {
+    const uint32_t j0 = it.win * ch_per_win, j1 = j0 + ch_per_win < nchunks ? j0 + ch_per_win : nchunks;
+    b_range<USE_BPOS>(bpos, b_rp, rows_b, j0, j1, k, lo, len);
+  };
+  Cur it_c, it_n, it_nn, it_n3;
+  uint32_t ks_c, ks_n, ks_nn, los_c, lens_c, los_n, lens_n;  // shared entry: current / next / next-next item
+  uint32_t ko_c, ko_n, ko_nn, loo_c, leno_c, loo_n, leno_n;  // owned entry
+  load_item(item_index(0), it_c);
+  load_item(item_index(1), it_n);
+  load_item(item_index(2), it_nn);
+  fetch_entry(it_c, ks_c, ko_c);
+  fetch_entry(it_n, ks_n, ko_n);
+  fetch_range(it_c, ks_c, los_c, lens_c);
+  fetch_range(it_c, ko_c, loo_c, leno_c);
+  while (it_c.live) {
+    unsigned int claimed = 0;
+    if (pos == 0 && threadIdx.x == 0) claimed = atomicAdd(queue, ITEM_RUN);
+    const uint32_t j0 = it_c.win * ch_per_win, j1 = j0 + ch_per_win < nchunks ? j0 + ch_per_win : nchunks;
+    const uint32_t c0 = it_c.win << WIN_SHIFT, cspan = (j1 - j0) << cw_shift;
+    fetch_range(it_n, ks_n, los_n, lens_n);
+    fetch_range(it_n, ko_n, loo_n, leno_n);
+    load_item(item_index(3), it_n3);
+    fetch_entry(it_nn, ks_nn, ko_nn);
+    RankWord* const words = reinterpret_cast<RankWord*>(bm);  // (PASS 0 addresses it as the plain bitmap it is)
+    wave_products<float, 0>(los_c, lens_c, 0.f, true, NW, wave, b_col, nullptr, c0, cspan, words, nullptr);
+    if (it_c.n_a <= (uint32_t)(64 + TPB)) {
+      if (it_c.n_a > 64)  // (uniform)
+        wave_products<float, 0>(loo_c, leno_c, 0.f, false, NW, wave, b_col, nullptr, c0, cspan, words, nullptr);
+    } else {
+      streamed_products<float, 0, USE_BPOS, NW>(a_col, nullptr, it_c.a_start, it_c.n_a, j0, j1, wave, b_rp, b_col, nullptr, bpos,
+                                               rows_b, c0, cspan, words, nullptr);
+    }
+    __syncthreads();  // the window's bitmap is complete
+    // nnz per numeric chunk; chunks are dealt round-robin (the dense ones are neighbours); the bitmap is cleared on the way
+    for (uint32_t c = wave; c < j1 - j0; c += NW) {
+      uint32_t n = 0;
+      for (uint32_t i = lane; i < cwords; i += 64) {
+        const uint32_t v = bm[c * cwords + i];
+        if (v) bm[c * cwords + i] = 0;
+        n += __popc(v);
+      }
+      n = wave_sum_dpp_u32(n);
+      if (lane == 0) hcnt[(uint64_t)it_c.hrow * nchunks + j0 + c] = n;
+    }
+    if (pos == 0 && threadIdx.x == 0) run_s = claimed;
+    __syncthreads();  // LDS is all zero again; the claimed run is visible
+    if (pos == 0) run_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_s);
+    if (++pos == ITEM_RUN) {
+      pos = 0;
+      run_base = run_next;
+      run_next = 0xFFFFFFFFu;
+    }
+    it_c = it_n, it_n = it_nn, it_nn = it_n3;
+    ks_c = ks_n, los_c = los_n, lens_c = lens_n;
+    ko_c = ko_n, loo_c = loo_n, leno_c = leno_n;
+    ks_n = ks_nn, ko_n = ko_nn;
+  }
+}
 
 struct HeavyItem {       // 32 bytes, read with scalar loads
   uint64_t a_start;      // first entry of A's row
@@ -1288,16 +1370,7 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
     }
   };
   auto fetch_range = [&](uint32_t j0, uint32_t j1, uint32_t k, uint32_t& lo, uint32_t& len) {
-    lo = 0, len = 0;
-    if (k != 0xFFFFFFFFu) {
-      if (USE_BPOS) {
-        lo = bpos[(uint64_t)j0 * rows_b + k];
-        len = bpos[(uint64_t)j1 * rows_b + k] - lo;
-      } else {
-        lo = (uint32_t)b_rp[k];
-        len = (uint32_t)b_rp[k + 1] - lo;
-      }
-    }
+    b_range<USE_BPOS>(bpos, b_rp, rows_b, j0, j1, k, lo, len);
   };
   HeavyItem it_c, it_n, it_nn, it_n3;  // descriptors are read two items before their entries are requested
   uint32_t ks_c, ks_n, ks_nn, los_c, lens_c, los_n, lens_n;  // shared entry: current / next / next-next item
@@ -1337,31 +1410,8 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
         if (it_c.n_a > 64)  // (uniform)
           wave_products<T, PASS>(loo_c, leno_c, ao_c, false, NW, wave, b_col, b_val, c0, cspan, words, vals);
       } else {
-        // streamed A row: after the shared head, wavefront w takes the 64-entry batches w, w + NW, ...; while batch i
-        // is multiplied the B-split lookups of batch i + 1 and the entries of batch i + 2 are in flight
-        const uint64_t ps = it_c.a_start + 64, pe = it_c.a_start + it_c.n_a;
-        const uint64_t nb = ((uint64_t)it_c.n_a - 64 + 63) >> 6;
-        auto s_entry = [&](uint64_t bb, uint32_t& k, T& a) {
-          const uint64_t p = ps + (bb << 6) + lane;
-          k = 0xFFFFFFFFu, a = T(0);
-          if (bb < nb && p < pe) {
-            k = a_col[p];
-            if (PASS == 2) a = a_val[p];
-          }
-        };
-        uint32_t k1, k2, lo1, len1;
-        T a1, a2;
-        s_entry(wave, k1, a1);
-        s_entry(wave + NW, k2, a2);
-        fetch_range(j0, j1, k1, lo1, len1);
-        for (uint64_t b = wave; b < nb; b += NW) {
-          const uint32_t lo_b = lo1, len_b = len1;
-          const T a_b = a1;
-          fetch_range(j0, j1, k2, lo1, len1);
-          a1 = a2;
-          s_entry(b + 2 * NW, k2, a2);
-          wave_products<T, PASS>(lo_b, len_b, a_b, false, NW, wave, b_col, b_val, c0, cspan, words, vals);
-        }
+        streamed_products<T, PASS, USE_BPOS, NW>(a_col, a_val, it_c.a_start, it_c.n_a, j0, j1, wave, b_rp, b_col, b_val, bpos,
+                                                 rows_b, c0, cspan, words, vals);
       }
     };
     all_products(std::integral_constant<int, 1>{});
@@ -2245,21 +2295,29 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     }
     SPAM_TRY(p->hcnt.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
     SPAM_TRY(p->hoff.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
-    const unsigned grid = std::min<uint32_t>(p->n_heavy, HEAVY_GRID);
     DevBuf sym_order, otmp;
     SPAM_TRY(sym_order.alloc((uint64_t)p->n_heavy * 4));
     SPAM_TRY(otmp.alloc(64 * 4));
     SPAM_TRY(order_by_cost(p->heavy_rows.as<uint32_t>(), p->n_heavy, fl, otmp.as<uint32_t>(), sym_order.as<uint32_t>(), s));
-    if (p->use_bpos)
-      sym_heavy_kernel<true><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, p->b_col, p->bpos.as<uint32_t>(),
-                                                   (uint32_t)b->rows, sym_order.as<uint32_t>(), p->n_heavy,
-                                                   p->hrow_of_row.as<uint32_t>(), p->nchunks, p->cw_shift,
-                                                   p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
-    else
-      sym_heavy_kernel<false><<<grid, 1024, 0, s>>>(a->row_ptr, a->col_idx, b->row_ptr, p->b_col, nullptr,
-                                                    (uint32_t)b->rows, sym_order.as<uint32_t>(), p->n_heavy,
-                                                    p->hrow_of_row.as<uint32_t>(), p->nchunks, p->cw_shift,
-                                                    p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
+    const uint64_t nwin = (b->cols + (1ull << 20) - 1) >> 20;  // 2^20-column bitmap windows per row
+    if ((uint64_t)p->n_heavy * nwin >= 0xFFFFFFFFull) return set_error(SPAM_E_UNSUPPORTED, "too many (heavy row, column window) pairs for the 32-bit work queue");
+    DevBuf sitems;
+    SPAM_TRY(sitems.alloc((uint64_t)p->n_heavy * sizeof(SymItem)));
+    sym_items_kernel<<<(p->n_heavy + 255) / 256, 256, 0, s>>>(sym_order.as<uint32_t>(), p->n_heavy, a->row_ptr,
+                                                            p->hrow_of_row.as<uint32_t>(), sitems.as<SymItem>());
+    SPAM_CHECK_LAUNCH();
+    {
+      const uint64_t n_sitems = (uint64_t)p->n_heavy * nwin;
+      const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)device_cus(), (n_sitems + ITEM_RUN - 1) / ITEM_RUN));
+      if (p->use_bpos)
+        sym_heavy_kernel<true, 1024><<<sgrid, 1024, 0, s>>>(a->col_idx, b->row_ptr, p->b_col, p->bpos.as<uint32_t>(), (uint32_t)b->rows,
+                                                          sitems.as<SymItem>(), p->n_heavy, (uint32_t)nwin, p->nchunks, p->cw_shift,
+                                                          p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
+      else
+        sym_heavy_kernel<false, 1024><<<sgrid, 1024, 0, s>>>(a->col_idx, b->row_ptr, p->b_col, nullptr, (uint32_t)b->rows,
+                                                           sitems.as<SymItem>(), p->n_heavy, (uint32_t)nwin, p->nchunks, p->cw_shift,
+                                                           p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
+    }
     SPAM_CHECK_LAUNCH();
     heavy_finalize_kernel<<<(p->n_heavy + 3) / 4, 256, 0, s>>>(p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
                                                               p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn);
