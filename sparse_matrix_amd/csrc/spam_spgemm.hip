@@ -526,6 +526,30 @@ __global__ __launch_bounds__(TPB) void num_row_kernel(
 
 // ---- heavy rows: B rows pre-split at numeric-chunk boundaries ---------------------------------------
 // bpos[j * rows_b + k] = first position q in B's row k with col[q] >= j * CW, j = 0..nchunks (absolute, u32).
+// Two kernels share the table: rows of up to BPOS_SHORT entries are walked by one lane each, chunk by chunk, so that the
+// 64 rows of a wavefront write 64 consecutive table entries per chunk (the table is chunk-major: written row by row
+// every entry is a 64-byte line of its own — 63 ms for the 8.6 GB table of a scale-22 B); longer rows (a few percent
+// of them, most of the entries) take one wavefront each, which finds the chunk boundaries among its lanes' entries.
+constexpr uint32_t BPOS_SHORT = 64;
+
+__global__ __launch_bounds__(256) void bpos_short_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
+                                                        uint32_t rows_b, uint32_t nchunks, int CW_SHIFT,
+                                                        uint32_t* __restrict__ bpos) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= rows_b) return;
+  const uint64_t s = b_rp[k], e = b_rp[k + 1];
+  if (e - s > BPOS_SHORT) return;
+  uint64_t q = s;
+  uint32_t nc = q < e ? b_col[q] >> CW_SHIFT : 0xFFFFFFFFu;  // chunk of the entry at q
+  for (uint32_t j = 0; j <= nchunks; ++j) {
+    while (nc < j) {
+      ++q;
+      nc = q < e ? b_col[q] >> CW_SHIFT : 0xFFFFFFFFu;
+    }
+    bpos[(uint64_t)j * rows_b + k] = (uint32_t)q;
+  }
+}
+
 __global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
                                                   uint32_t rows_b, uint32_t nchunks, int CW_SHIFT,
                                                   uint32_t* __restrict__ bpos) {
@@ -534,6 +558,7 @@ __global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ 
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t k = wave; k < rows_b; k += nwaves) {
     const uint64_t s = b_rp[k], e = b_rp[k + 1];
+    if (e - s <= BPOS_SHORT) continue;  // bpos_short_kernel's
     for (uint64_t q = s + lane; q < e; q += 64) {
       const uint32_t cq = b_col[q] >> CW_SHIFT;
       const uint32_t cp = (q == s) ? 0u : (b_col[q - 1] >> CW_SHIFT);
@@ -793,12 +818,16 @@ struct RankWord {  // one bitmap word of the group's column span
 template <class T, int PASS, int U>
 __device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[U], const T (&prods)[U], uint32_t c0,
                                                  uint32_t cspan, RankWord* words, T* vals) {
-  if (PASS == 0) {  // symbolic phase: `words` is a plain bitmap, one bit per column of the window
+  if (PASS == 0) {
+    // symbolic phase: `words` is a plain bitmap, one bit per column of the window — transposed inside every block of
+    // 4096 columns (128 words): column r of the block is bit r / 128 of word r % 128.  Only the bit COUNT of a chunk (a
+    // whole number of blocks) is read back, and the 64 consecutive columns of a dense B row's piece then go to 64
+    // different words instead of two (same-address LDS atomics serialise: 59 % of the LDS busy time before).
     uint32_t* bm = reinterpret_cast<uint32_t*>(words);
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const uint32_t rel = cols[j] - c0;
-      if (cols[j] != EMPTY_KEY && rel < cspan) atomicOr(&bm[rel >> 5], 1u << (rel & 31));
+      if (cols[j] != EMPTY_KEY && rel < cspan) atomicOr(&bm[((rel >> 12) << 7) | (rel & 127u)], 1u << ((rel >> 7) & 31u));
     }
   } else if (PASS == 1) {
 #pragma unroll
@@ -1067,16 +1096,15 @@ __global__ __launch_bounds__(256) void sym_items_kernel(const uint32_t* __restri
   items[i] = it;
 }
 
-template <bool USE_BPOS, int TPB>
-__global__ __launch_bounds__(TPB) void sym_heavy_kernel(const uint32_t* __restrict__ a_col, const uint64_t* __restrict__ b_rp,
+template <bool USE_BPOS, int TPB, int WIN_SHIFT_, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(TPB, WAVES_PER_SIMD) void sym_heavy_kernel(const uint32_t* __restrict__ a_col, const uint64_t* __restrict__ b_rp,
                                                        const uint32_t* __restrict__ b_col, const uint32_t* __restrict__ bpos,
                                                        uint32_t rows_b, const SymItem* __restrict__ items, uint32_t n_rows,
                                                        uint32_t nwin, uint32_t nchunks, int cw_shift,
                                                        uint32_t* __restrict__ hcnt, uint32_t* __restrict__ queue) {
   constexpr int NW = TPB / 64;
-  constexpr uint32_t BM_WORDS = TPB * 32;                       // 128 KB at 1024 threads
-  constexpr uint32_t WIN_SHIFT = TPB == 1024 ? 20 : TPB == 512 ? 19 : 18;
-  static_assert(BM_WORDS * 32u == (1u << WIN_SHIFT), "window = 1024 columns per thread");
+  constexpr uint32_t WIN_SHIFT = WIN_SHIFT_;
+  constexpr uint32_t BM_WORDS = (1u << WIN_SHIFT) / 32;         // 128 KB for 2^20 columns
   __shared__ __attribute__((aligned(16))) uint32_t bm[BM_WORDS];
   __shared__ uint32_t run_s;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -2290,6 +2318,9 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     if (p->use_bpos) {
       SPAM_TRY(p->bpos.alloc((uint64_t)(p->nchunks + 1) * b->rows * 4));
       unsigned grid = (unsigned)std::min<uint64_t>((b->rows + 3) / 4, 16384);
+      bpos_short_kernel<<<(unsigned)((b->rows + 255) / 256), 256, 0, s>>>(b->row_ptr, p->b_col, (uint32_t)b->rows, p->nchunks,
+                                                                          p->cw_shift, p->bpos.as<uint32_t>());
+      SPAM_CHECK_LAUNCH();
       bpos_kernel<<<grid, 256, 0, s>>>(b->row_ptr, p->b_col, (uint32_t)b->rows, p->nchunks, p->cw_shift, p->bpos.as<uint32_t>());
       SPAM_CHECK_LAUNCH();
     }
@@ -2299,25 +2330,47 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     SPAM_TRY(sym_order.alloc((uint64_t)p->n_heavy * 4));
     SPAM_TRY(otmp.alloc(64 * 4));
     SPAM_TRY(order_by_cost(p->heavy_rows.as<uint32_t>(), p->n_heavy, fl, otmp.as<uint32_t>(), sym_order.as<uint32_t>(), s));
-    const uint64_t nwin = (b->cols + (1ull << 20) - 1) >> 20;  // 2^20-column bitmap windows per row
+    // geometry of the symbolic heavy kernel (SPAM_SYM_GEOM): 0 = 1024 threads, 2^20-column windows, one workgroup per
+    // CU; 1 = 512 threads, 2^19 columns, two per CU; 2 = 1024 threads, 2^19 columns, two per CU (8 waves per SIMD); 3 = 512 threads, 2^18 columns, four per CU
+    static const int sym_geom_env = [] { const char* e = getenv("SPAM_SYM_GEOM"); return e ? atoi(e) : -1; }();
+    // (scale-20 A*A: 28.7 / 27.8 / 24.8 / 24.2 ms of symbolic phase; every window costs two B-split lookups per entry of
+    // A's row, so wide matrices take the larger windows)
+    const int sym_geom = sym_geom_env >= 0 && sym_geom_env <= 3 ? sym_geom_env
+                         : b->cols <= (16ull << 18) ? 3 : b->cols <= (32ull << 19) ? 2 : 0;
+    const int win_shift = sym_geom == 0 ? 20 : sym_geom == 3 ? 18 : 19;
+    const uint64_t nwin = (b->cols + (1ull << win_shift) - 1) >> win_shift;  // bitmap windows per row
     if ((uint64_t)p->n_heavy * nwin >= 0xFFFFFFFFull) return set_error(SPAM_E_UNSUPPORTED, "too many (heavy row, column window) pairs for the 32-bit work queue");
     DevBuf sitems;
     SPAM_TRY(sitems.alloc((uint64_t)p->n_heavy * sizeof(SymItem)));
     sym_items_kernel<<<(p->n_heavy + 255) / 256, 256, 0, s>>>(sym_order.as<uint32_t>(), p->n_heavy, a->row_ptr,
                                                             p->hrow_of_row.as<uint32_t>(), sitems.as<SymItem>());
     SPAM_CHECK_LAUNCH();
+#define SPAM_SYM_HEAVY_G(BPOS_, TPB_, WS_, WPS_)                                                                     \
+  do {                                                                                                               \
+    auto kern = sym_heavy_kernel<BPOS_, TPB_, WS_, WPS_>;                                                            \
+    int per_cu = 0;                                                                                                  \
+    SPAM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, TPB_, 0));                              \
+    if (per_cu < 1) per_cu = 1;                                                                                      \
+    const uint64_t n_sitems = (uint64_t)p->n_heavy * nwin;                                                           \
+    const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * device_cus(), (n_sitems + ITEM_RUN - 1) / ITEM_RUN)); \
+    if (dbg_sym) fprintf(stderr, "[spam dbg] symbolic heavy: %d threads, 2^%d columns, %d workgroups per CU, grid %u\n", TPB_, WS_, per_cu, sgrid); \
+    kern<<<sgrid, TPB_, 0, s>>>(a->col_idx, b->row_ptr, p->b_col, BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, \
+                                sitems.as<SymItem>(), p->n_heavy, (uint32_t)nwin, p->nchunks, p->cw_shift,          \
+                                p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);                                  \
+  } while (0)
+#define SPAM_SYM_HEAVY(BPOS_)                                                                                        \
+  do {                                                                                                               \
+    if (sym_geom == 0) SPAM_SYM_HEAVY_G(BPOS_, 1024, 20, 4);                                                         \
+    else if (sym_geom == 1) SPAM_SYM_HEAVY_G(BPOS_, 512, 19, 4);                                                     \
+    else if (sym_geom == 2) SPAM_SYM_HEAVY_G(BPOS_, 1024, 19, 8);                                                    \
+    else SPAM_SYM_HEAVY_G(BPOS_, 512, 18, 8);                                                                        \
+  } while (0)
     {
-      const uint64_t n_sitems = (uint64_t)p->n_heavy * nwin;
-      const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)device_cus(), (n_sitems + ITEM_RUN - 1) / ITEM_RUN));
-      if (p->use_bpos)
-        sym_heavy_kernel<true, 1024><<<sgrid, 1024, 0, s>>>(a->col_idx, b->row_ptr, p->b_col, p->bpos.as<uint32_t>(), (uint32_t)b->rows,
-                                                          sitems.as<SymItem>(), p->n_heavy, (uint32_t)nwin, p->nchunks, p->cw_shift,
-                                                          p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
-      else
-        sym_heavy_kernel<false, 1024><<<sgrid, 1024, 0, s>>>(a->col_idx, b->row_ptr, p->b_col, nullptr, (uint32_t)b->rows,
-                                                           sitems.as<SymItem>(), p->n_heavy, (uint32_t)nwin, p->nchunks, p->cw_shift,
-                                                           p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);
+      static const bool dbg_sym = [] { const char* e = getenv("SPAM_DBG_HEAVY"); return e && (atoi(e) & 64); }();
+      if (p->use_bpos) SPAM_SYM_HEAVY(true); else SPAM_SYM_HEAVY(false);
     }
+#undef SPAM_SYM_HEAVY
+#undef SPAM_SYM_HEAVY_G
     SPAM_CHECK_LAUNCH();
     heavy_finalize_kernel<<<(p->n_heavy + 3) / 4, 256, 0, s>>>(p->heavy_rows.as<uint32_t>(), p->n_heavy, p->nchunks,
                                                               p->hcnt.as<uint32_t>(), p->hoff.as<uint32_t>(), rn);
