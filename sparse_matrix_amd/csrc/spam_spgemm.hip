@@ -2332,7 +2332,8 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     SPAM_TRY(order_by_cost(p->heavy_rows.as<uint32_t>(), p->n_heavy, fl, otmp.as<uint32_t>(), sym_order.as<uint32_t>(), s));
     // geometry of the symbolic heavy kernel (SPAM_SYM_GEOM): 0 = 1024 threads, 2^20-column windows, one workgroup per
     // CU; 1 = 512 threads, 2^19 columns, two per CU; 2 = 1024 threads, 2^19 columns, two per CU (8 waves per SIMD); 3 = 512 threads, 2^18 columns, four per CU
-    static const int sym_geom_env = [] { const char* e = getenv("SPAM_SYM_GEOM"); return e ? atoi(e) : -1; }();
+    const char* sym_geom_cfg = getenv("SPAM_SYM_GEOM");  // (read per call: the tests run every geometry in one process)
+    const int sym_geom_env = sym_geom_cfg ? atoi(sym_geom_cfg) : -1;
     // (scale-20 A*A: 28.7 / 27.8 / 24.8 / 24.2 ms of symbolic phase; every window costs two B-split lookups per entry of
     // A's row, so wide matrices take the larger windows)
     const int sym_geom = sym_geom_env >= 0 && sym_geom_env <= 3 ? sym_geom_env

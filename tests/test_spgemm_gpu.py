@@ -6,6 +6,8 @@ per-row set-equal without (the reference's own test compares order-insensitively
 spam_csr/src/tests.rs:356-371); f64 values within 1e-10 relative on positive data, Higham's bound
 (spam_dok/src/lib.rs:56-92) on signed data.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -65,15 +67,15 @@ def test_rmat_multi_chunk(spam, oracle):
 
 
 def test_wide_b_many_symbolic_chunks(spam, oracle):
-    """B with 300 000 columns: 3 symbolic chunks of 131 072 and 19 numeric chunks per heavy row."""
+    """B with 300 000 columns: 2 symbolic bitmap windows and 37 numeric chunks per heavy row."""
     ma = synth.random_csr(16, 500, 0.5, seed=11, signed=False)
     mb = synth.random_csr(500, 300_000, 0.002, seed=12, signed=False)
     _both(spam, oracle, ma, mb, F64_RTOL)
 
 
 def test_very_wide_b_several_bitmap_windows(spam, oracle):
-    """B with 2.5 M columns: 153 numeric chunks and 3 symbolic bitmap windows of 2^20 columns per heavy row, rows of
-    C with ~450 k entries; all three output orders."""
+    """B with 2.5 M columns: 306 numeric chunks of 8192 and 10 symbolic bitmap windows of 2^18 columns per heavy row,
+    rows of C with ~450 k entries; all three output orders."""
     ma = synth.random_csr(6, 2000, 0.25, seed=41, signed=False)
     mb = synth.random_csr(2000, 2_500_000, 0.0004, seed=42, signed=False)
     C = _both(spam, oracle, ma, mb, F64_RTOL)
@@ -91,6 +93,31 @@ def test_very_wide_b_beyond_2_pow_24_columns(spam, oracle, cols):
     C = _both(spam, oracle, ma, mb, F64_RTOL)
     assert np.diff(C.offsets.astype(np.int64)).max() > 4096
     _exact_unsorted(spam, oracle, ma, mb)
+
+
+@pytest.mark.parametrize("sym_geom", [0, 1, 2, 3])
+@pytest.mark.parametrize("heavy_tpb", [256, 512, 1024])
+def test_heavy_path_geometries(spam, oracle, sym_geom, heavy_tpb):
+    """Every geometry of the symbolic heavy kernel (window width / workgroup size, SPAM_SYM_GEOM) and of the numeric one
+    (SPAM_HEAVY_TPB), which the library otherwise picks from the matrix width: 3 M columns = 3 to 12 bitmap windows per
+    row; A rows of 4 entries (shared head only) and of ~1000 entries (owned and streamed batches)."""
+    saved = {k: os.environ.get(k) for k in ("SPAM_SYM_GEOM", "SPAM_HEAVY_TPB")}
+    os.environ["SPAM_SYM_GEOM"], os.environ["SPAM_HEAVY_TPB"] = str(sym_geom), str(heavy_tpb)
+    try:
+        ma = synth.random_csr(4, 1000, 0.004, seed=61, signed=False)
+        mb = synth.random_csr(1000, 3_000_000, 5000 / 3_000_000, seed=62, signed=False)
+        C = _both(spam, oracle, ma, mb, F64_RTOL)
+        assert np.diff(C.offsets.astype(np.int64)).max() > 4096
+        ma = synth.random_csr(3, 2000, 0.5, seed=63, signed=False)
+        mb = synth.random_csr(2000, 600_000, 30 / 600_000, seed=64, signed=False)
+        C = _both(spam, oracle, ma, mb, F64_RTOL)
+        assert np.diff(C.offsets.astype(np.int64)).max() > 4096
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_unsorted_b_heavy_rows_filter_path(spam, oracle):
