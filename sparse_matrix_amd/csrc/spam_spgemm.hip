@@ -815,6 +815,10 @@ struct RankWord {  // one bitmap word of the group's column span
 };
 
 // One round of WAVE_U products per lane.  PASS 0 (symbolic) / 1: mark the columns; PASS 2: add the products at their rank.
+// A lane without a product passes the column c0 - 1 (no_col): relative to the window that is 0xFFFFFFFF, outside like
+// any column the B-split did not filter, so one compare serves both.
+__device__ __forceinline__ uint32_t no_col(uint32_t c0) { return c0 - 1u; }
+
 template <class T, int PASS, int U>
 __device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[U], const T (&prods)[U], uint32_t c0,
                                                  uint32_t cspan, RankWord* words, T* vals) {
@@ -827,13 +831,13 @@ __device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[U], cons
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const uint32_t rel = cols[j] - c0;
-      if (cols[j] != EMPTY_KEY && rel < cspan) atomicOr(&bm[((rel >> 12) << 7) | (rel & 127u)], 1u << ((rel >> 7) & 31u));
+      if (rel < cspan) atomicOr(&bm[((rel >> 12) << 7) | (rel & 127u)], 1u << ((rel >> 7) & 31u));
     }
   } else if (PASS == 1) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const uint32_t rel = cols[j] - c0;
-      if (cols[j] != EMPTY_KEY && rel < cspan) atomicOr(&words[rel >> 5].bits, 1u << (rel & 31));
+      if (rel < cspan) atomicOr(&words[rel >> 5].bits, 1u << (rel & 31));
     }
   } else {
     RankWord w[U];
@@ -841,8 +845,7 @@ __device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[U], cons
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const uint32_t rel = cols[j] - c0;
-      w[j].prefix = 0, w[j].bits = 0;
-      if (cols[j] != EMPTY_KEY && rel < cspan) w[j] = words[rel >> 5];  // all reads in flight together
+      w[j] = words[rel < cspan ? rel >> 5 : 0u];  // unconditional (word 0 for the idle lanes): all reads in flight together
     }
     // the ranks first, unconditionally and in straight-line code, the adds afterwards: an add issued between two rank
     // computations makes the next one's wait for its word (lgkmcnt) wait for that add's round trip as well
@@ -854,7 +857,7 @@ __device__ __forceinline__ void accumulate_round(const uint32_t (&cols)[U], cons
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const uint32_t rel = cols[j] - c0;
-      if (cols[j] != EMPTY_KEY && rel < cspan) lds_add(&vals[slot[j]], prods[j]);
+      if (rel < cspan) lds_add(&vals[slot[j]], prods[j]);
     }
   }
 }
@@ -909,7 +912,7 @@ __device__ __forceinline__ void long_pieces(uint32_t lo, uint32_t len, T av, uin
         const uint32_t qj = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)dl);
         const uint32_t nj = (64 % PU == 0 || r + j < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)n, (int)dl) : 0u;
         sa[j] = PASS == 2 ? readlane_val(a, dl) : T(0);
-        cols[j] = EMPTY_KEY;
+        cols[j] = no_col(c0);
         prods[j] = T(0);
         if (lane < nj) {
           const uint64_t q = (uint64_t)qj + lane;
@@ -940,11 +943,22 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
                                               uint32_t cspan, RankWord* words, T* vals) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t lmask = __ballot(len >= LONG_SEG);
-  const uint32_t slen = (len >= LONG_SEG || (shared && (lane % nw) != wave)) ? 0u : len;  // this lane's short segment
+  // this lane's short segment.  Of the shared entries a wavefront takes the short segments of the lanes wave, wave + nw,
+  // ...: they are moved to the lanes 0 .. 64 / nw - 1 first, so that the segment search below bisects over the 64 / nw
+  // candidates instead of over lane indices nw apart (three halvings less per round)
+  uint32_t slen = len >= LONG_SEG ? 0u : len, flo = lo;
+  T fav = av;
+  if (shared) {
+    const uint32_t src = (lane * nw + wave) & 63;
+    const uint32_t l2 = shfl_u32(slen, src);
+    flo = shfl_u32(lo, src);
+    if (PASS == 2) fav = shfl_val(av, src);
+    slen = lane < 64 / nw ? l2 : 0u;
+  }
   const uint32_t inc = wave_incl_scan_u32(slen);
   const uint32_t st = inc - slen;                        // first product index of this lane's segment
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-  const uint32_t off = lo - st;                          // q = off[s] + idx for a product index idx of segment s
+  const uint32_t off = flo - st;                         // q = off[s] + idx for a product index idx of segment s
   // one round of the short segments, in two halves: the segment search and the loads ...
   auto issue = [&](uint32_t base, uint32_t (&slo)[WAVE_U], uint32_t (&cols)[WAVE_U], T (&bv)[WAVE_U]) {
     // st is non-decreasing over the lanes: the lanes with st <= w form a prefix whose last member is the segment
@@ -985,7 +999,7 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
 #pragma unroll
     for (int j = 0; j < WAVE_U; ++j) {
       const uint32_t idx = base + 64 * j + lane;
-      cols[j] = EMPTY_KEY;
+      cols[j] = no_col(c0);
       bv[j] = T(0);
       if (idx < total) {
         cols[j] = b_col[qq[j] + idx];
@@ -997,7 +1011,7 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
   auto finish = [&](const uint32_t (&slo)[WAVE_U], const uint32_t (&cols)[WAVE_U], const T (&bv)[WAVE_U]) {
     T aa[WAVE_U], prods[WAVE_U];
 #pragma unroll
-    for (int j = 0; j < WAVE_U; ++j) aa[j] = PASS == 2 ? shfl_val(av, slo[j]) : T(0);
+    for (int j = 0; j < WAVE_U; ++j) aa[j] = PASS == 2 ? shfl_val(fav, slo[j]) : T(0);
 #pragma unroll
     for (int j = 0; j < WAVE_U; ++j) prods[j] = aa[j] * bv[j];  // t * t1 (mul_hash.rs:154)
     accumulate_round<T, PASS, WAVE_U>(cols, prods, c0, cspan, words, vals);
