@@ -1522,10 +1522,18 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
     // columns: every lane expands its own words (a loop over the word's set bits; adjacent lanes hold adjacent words, so
     // the stores of one step land in one stretch of C).  Two alternatives measured slower: 32 lanes per word with the
     // word broadcast by ds_bpermute (30.8 k cycles per item against 11.7 k) or re-read from LDS (16.5 k).
-    for (uint32_t i0 = wave * wpw; i0 < (wave + 1) * wpw; i0 += 64) {
-      const uint32_t i = i0 + lane;
-      if (i < (wave + 1) * wpw) {
-        const RankWord w = words[i];
+    {
+      const uint32_t wend = (wave + 1) * wpw;
+      auto word_at = [&](uint32_t i) {
+        RankWord w;
+        w.prefix = 0, w.bits = 0;
+        if (i < wend) w = words[i];
+        return w;
+      };
+      RankWord w = word_at(wave * wpw + lane);
+      for (uint32_t i0 = wave * wpw; i0 < wend; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const RankWord wn = word_at(i + 64);  // the next step's word: its LDS round trip overlaps this step's stores
         if (w.bits) {
           uint32_t bits = w.bits;
           uint64_t o = out + w.prefix;
@@ -1540,6 +1548,7 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
           z.prefix = 0, z.bits = 0;
           words[i] = z;
         }
+        w = wn;
       }
     }
     if (pos == 0 && threadIdx.x == 0) run_s = claimed;
