@@ -826,6 +826,32 @@ struct GatherSliced {
   }
 };
 
+// The three cases of GatherSliced as types of their own: the pipelined kernel picks one per part and tile, OUTSIDE the
+// unrolled gather loop of tile_issue.  With the (uniform) case distinction inside the functor the compiler kept a
+// branch per gather, every gather in a basic block of its own, and waited for each (vmcnt(0)) before issuing the next.
+template <class T>
+struct GatherCold {
+  const T SPAM_GLB* __restrict__ base;
+  __device__ __forceinline__ T operator()(uint32_t c) const { return __builtin_nontemporal_load(base + c); }
+};
+template <class T>
+struct GatherTable {
+  const T SPAM_GLB* __restrict__ base;
+  __device__ __forceinline__ T operator()(uint32_t c) const { return base[c]; }
+};
+template <class T>
+struct GatherLevel {  // slots below L from the LDS copy of the table's head, the others from the table (see GatherSliced)
+  const T SPAM_GLB* __restrict__ base;
+  const T* lds;
+  uint32_t L;
+  __device__ __forceinline__ T operator()(uint32_t c) const {
+    const bool in_lds = c < L;
+    const T g = base[in_lds ? 0u : c];
+    const T l = lds[in_lds ? c : 0u];
+    return in_lds ? l : g;
+  }
+};
+
 // Persistent workgroups: each learns the XCD it runs on, works through that XCD's slab queue (its gathers then hit
 // the slab table in the local L2, the hottest L slots in LDS), and afterwards helps the other slabs finish.
 template <class T, int TPB, int NPT, bool LDS, int PROF = 0>
@@ -906,8 +932,16 @@ __global__ __launch_bounds__(TPB) void spmv_sliced_pipe_kernel(const SlabDesc<T>
     __syncthreads();
     uint32_t t_cur = s_t[0], t_next = s_t[1];
     __syncthreads();
+    auto issue = [&](uint32_t t) {  // (one straight-line instance of tile_issue per gather kind)
+      if (cold)
+        tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, GatherCold<T>{gx.base}, fo, t);
+      else if (gx.L == 0)
+        tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, GatherTable<T>{gx.base}, fo, t);
+      else
+        tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, GatherLevel<T>{gx.base, gx.lds, gx.L}, fo, t);
+    };
     bool loaded = t_cur < nfull;
-    if (loaded) tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, gx, fo, t_cur);
+    if (loaded) issue(t_cur);
     while (t_cur < sd.ntiles) {
       uint32_t t_nn = 0;
       if (threadIdx.x == 0) {
@@ -923,7 +957,7 @@ __global__ __launch_bounds__(TPB) void spmv_sliced_pipe_kernel(const SlabDesc<T>
         __syncthreads();
         if (PROF == 1) q2 = clock64();
         loaded = t_next < nfull;
-        if (loaded) tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, gx, fo, t_next);
+        if (loaded) issue(t_next);
         if (PROF == 1) q3 = clock64();
         const uint64_t base = (uint64_t)t_cur * TILE;
         if (PROF != 2)  // 2: experiment, loads and products only (wrong results)
@@ -940,7 +974,7 @@ __global__ __launch_bounds__(TPB) void spmv_sliced_pipe_kernel(const SlabDesc<T>
       } else {
         spmv_tile_body<T, uint32_t, TPB, NPT, true>(sm, row_ptr, col, val, gx, y, fo, carry, sd.nnz, t_cur);
         loaded = t_next < nfull;
-        if (loaded) tile_issue<T, uint32_t, TPB, NPT, true>(r, row_ptr, col, val, gx, fo, t_next);
+        if (loaded) issue(t_next);
       }
       long long q6 = 0;
       if (PROF == 1) q6 = clock64();
