@@ -5,7 +5,8 @@
 //   rows_to_threads  :38-64   -> spgemm_flops_kernel; partition rule in part_points_kernel (spam_rows_to_parts*,
 //                                spam_spgemm_rank_step)
 //   mul_hash_symbolic:66-103  -> sym_hash_kernel (rows of <= 512 products, several rows per workgroup),
-//                                sym_row_kernel (<= 4096, one row per workgroup), sym_heavy_kernel (bitmap windows)
+//                                sym_row_kernel (<= 4096, one row per workgroup), sym_heavy_kernel (bitmap windows in
+//                                LDS, the product streaming of the numeric heavy kernel)
 //   checked_inclusive_scan (lib.rs:267-274) -> scan_u32_to_u64
 //   mul_hash_numeric :106-201 -> num_hash_kernel / num_row_kernel (LDS linprobe map: u32 keys + T values, atomicCAS
 //                                claim + LDS atomic add) for rows of up to 4096 entries; beyond: heavy_groups_kernel
@@ -43,7 +44,10 @@ constexpr uint64_t WIDE_B_CHUNKS = 8192;        // more 2^13-column chunks than 
 // LDS accumulator of the heavy numeric path: 144 bytes per thread (two 512-thread workgroups per CU)
 __host__ __device__ constexpr uint32_t heavy_region_bytes(int tpb) { return (uint32_t)tpb * 144u; }
 
-constexpr uint32_t HEAVY_GRID = 8192;           // persistent workgroups of the symbolic heavy kernels (1 fits per CU)
+constexpr uint32_t HEAVY_GRID = 8192;           // upper bound of the grids of the heavy-row helper kernels
+// symbolic heavy kernel: 512 threads per (row, 2^18-column window) item, four workgroups per CU (8 waves per SIMD);
+// 1024 threads / 2^19 columns for B wider than 4 M columns, 1024 / 2^20 (one per CU) beyond 16 M.  SPAM_SYM_GEOM =
+// 0..3 forces one (tests, A/B runs).
 
 constexpr int NSYM = 4;                         // symbolic bins by F
 constexpr uint64_t SYM_MAX[NSYM - 1] = {64, 512, 4096};
