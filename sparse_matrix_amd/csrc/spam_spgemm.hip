@@ -166,9 +166,21 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 }
 
 // ---- linprobe in LDS --------------------------------------------------------------------------------
+// Home slot of a key.  FIB = false: linprobe's (key * 107) & mask (lib.rs:13-14) — it maps columns c and c + size to
+// the same slot, and R-MAT rows hold many such pairs, so linear probing degenerates into long runs.  FIB = true:
+// Fibonacci hashing on the top bits; the tables of the hash bins use it (scale-20 A*A: the two one-row-per-workgroup
+// numeric kernels 5.4 + 3.1 -> 3.0 + 1.7 ms).  Which slot a key lands in is visible only as the order of an UNSORTED
+// output row (sort_rows = 0, compared as a set, tests.rs:356-371); the reference's exact slot order is sort_rows = 2,
+// computed by ref_order_kernel with linprobe's own hash.
+template <bool FIB>
+__device__ __forceinline__ uint32_t home_slot(uint32_t key, uint32_t mask) {
+  return FIB ? ((key * 0x9E3779B1u) >> (__clz(mask))) & mask : (key * HASH_SCAL) & mask;
+}
+constexpr bool BIN_FIB = true;
+
 // linprobe::HashSet::insert (set.rs:128-160) with the claim made atomic: returns true when the key is new.
 __device__ __forceinline__ bool lds_set_insert(uint32_t* table, uint32_t mask, uint32_t key) {
-  uint32_t h = (key * HASH_SCAL) & mask;
+  uint32_t h = home_slot<BIN_FIB>(key, mask);
   for (;;) {
     const uint32_t old = atomicCAS(&table[h], EMPTY_KEY, key);
     if (old == EMPTY_KEY) return true;
@@ -178,11 +190,9 @@ __device__ __forceinline__ bool lds_set_insert(uint32_t* table, uint32_t mask, u
 }
 // linprobe::HashMap::entry + and_modify/or_insert (map.rs:67-120; mul_hash.rs:157-161).  Values start at 0,
 // so "first product stored" and "+= product" are the same atomic add.
-// FIB = true replaces linprobe's multiplier 107 (which maps columns c and c + size to the same slot; R-MAT rows
-// hold many such pairs and linear probing then degenerates into long runs) by Fibonacci hashing on the top bits.
-template <class T, bool FIB = false>
+template <class T, bool FIB = BIN_FIB>
 __device__ __forceinline__ void lds_map_upsert(uint32_t* keys, T* vals, uint32_t mask, uint32_t key, T v) {
-  uint32_t h = FIB ? ((key * 0x9E3779B1u) >> (__clz(mask))) & mask : (key * HASH_SCAL) & mask;
+  uint32_t h = home_slot<FIB>(key, mask);
   for (;;) {
     const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, key);
     if (old == EMPTY_KEY || old == key) {
@@ -198,7 +208,7 @@ __device__ __forceinline__ uint32_t lds_set_insert_batch(uint32_t* table, uint32
   uint32_t h[U], old[U], added = 0;
 #pragma unroll
   for (int j = 0; j < U; ++j) {
-    h[j] = (k[j] * HASH_SCAL) & mask;
+    h[j] = home_slot<BIN_FIB>(k[j], mask);
     old[j] = k[j] != EMPTY_KEY ? atomicCAS(&table[h[j]], EMPTY_KEY, k[j]) : k[j];
   }
 #pragma unroll
@@ -231,7 +241,7 @@ __device__ __forceinline__ void lds_map_upsert_batch(uint32_t* keys, T* vals, ui
   uint32_t h[U], old[U];
 #pragma unroll
   for (int j = 0; j < U; ++j) {
-    h[j] = FIB ? ((k[j] * 0x9E3779B1u) >> (__clz(mask))) & mask : (k[j] * HASH_SCAL) & mask;
+    h[j] = home_slot<FIB>(k[j], mask);
     old[j] = ok[j] ? atomicCAS(&keys[h[j]], EMPTY_KEY, k[j]) : k[j];
   }
 #pragma unroll
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(TPB) void num_row_kernel(
         bool okv[ROW_U];
 #pragma unroll
         for (int j = 0; j < ROW_U; ++j) okv[j] = cols[j] != EMPTY_KEY;
-        lds_map_upsert_batch<T, ROW_U, false>(keys, vals, mask, cols, prods, okv);
+        lds_map_upsert_batch<T, ROW_U, BIN_FIB>(keys, vals, mask, cols, prods, okv);
       }
       __syncthreads();
     }
