@@ -16,8 +16,8 @@
 //
 // Where the CPU code gives each thread a contiguous flop-balanced row range (mul_hash.rs:52-62), the GPU bins rows
 // by work: by F (intermediate products) for the symbolic pass, by nnz(C_i) for the numeric pass.  A bin fixes the
-// lanes per row (16 / 64 / 256 / 1024) and the LDS table size; the hash bins keep linprobe's hash (key * 107) &
-// (size - 1), its sentinel u32::MAX and its sizing max(16, 2 * next_pow2(n)).  Rows whose table would not fit LDS
+// lanes per row (16 / 64 / 256 / 1024) and the LDS table size; the hash bins keep linprobe's sentinel
+// u32::MAX and its sizing max(16, 2 * next_pow2(n)) but hash with Fibonacci's constant (see home_slot).  Rows whose table would not fit LDS
 // take the "heavy" path: the column range is cut into chunks, B's sorted rows are pre-split at the chunk boundaries
 // (bpos) so a chunk range touches only its own products, a row's chunks are packed into groups that fit the LDS
 // accumulator, and every (row, group) becomes a work item of a device-wide queue ordered by column window (see the
