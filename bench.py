@@ -348,7 +348,7 @@ def main():
         log(f"[spgemm {scale}] rank block rows [{offs0[rank]},{offs0[rank + 1]}) nnz {blk.nnz} generated in {time.time() - t0:.1f}s")
         xfer = {}
 
-        def one_step():
+        def one_step(sort_rows=False):
             """all-gather B (vals in flight during the symbolic phase), flop-balanced row block of A, two-phase SpGEMM.
             Returns (C, stats)."""
             g = spdist.allgather_csr(blk.row_ptr, blk.col_idx, blk.vals, offs0, rank, world, dist, async_vals=True)
@@ -367,7 +367,7 @@ def main():
                 Ablk = B
             plan, _ = Ablk.spgemm_symbolic(B)
             g.wait_values()
-            C, st = DeviceCsr.spgemm_numeric(plan, sort_rows=False)
+            C, st = DeviceCsr.spgemm_numeric(plan, sort_rows=sort_rows)
             C._keep = (C._keep, B, Ablk, g)
             return C, st
 
@@ -414,6 +414,17 @@ def main():
                               "stream_model_bytes": 16 * st["flops_f"] + 16 * st["nnz_a"] + 12 * st["nnz_c"]}
         log(f"[spgemm {scale}] {t_step * 1e3:.1f} ms/step, F={F:.3e}, nnzC={nnz_c:.3e}, "
             f"{sg['value']} Mnnz/s, {sg['gflops']} GFLOP/s")
+        # the B2 = true variant (rows of C sorted by column, mul_hash.rs:164-175): one more step, informational
+        if C is not None:
+            C.free()
+        barrier()
+        t0 = time.perf_counter()
+        C, st_sorted = one_step(sort_rows=True)
+        barrier()
+        t_sorted = max_over_ranks(time.perf_counter() - t0)
+        sg["sorted_out"] = {"ms_per_step": round(t_sorted * 1e3, 2), "Mnnz_out_per_s": round(nnz_c / t_sorted / 1e6, 1),
+                            "steps": 1, "note": "B2 = true: rows of up to 4096 entries are sorted in LDS after the numeric "
+                                                "phase; longer rows come out in column order anyway"}
         # a first call: nothing cached in the library's allocator (hipMalloc of the output inside the step)
         if world == 1:
             keep = C
