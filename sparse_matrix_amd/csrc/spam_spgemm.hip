@@ -1607,25 +1607,34 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void sort_rows_kernel(const ui
   const uint32_t row = valid ? rows_list[ridx] : 0;
   const uint64_t s = valid ? c_rp[row] : 0;
   const uint32_t n = valid ? (uint32_t)(c_rp[row + 1] - s) : 0;
-  for (uint32_t i = gl; i < CAP; i += G) {
+  // the network covers next_pow2(longest row of the workgroup) slots, and every lane takes whole compare-exchange
+  // pairs (pair p of a stage with distance j: i = p with a zero bit inserted at j, partner i | j)
+  uint32_t cap = next_pow2_u32(n < 2 ? 2 : n);
+  if (RPW > 1) {
+    __shared__ uint32_t cap_s;
+    if (threadIdx.x == 0) cap_s = 0;
+    __syncthreads();
+    atomicMax(&cap_s, cap);
+    __syncthreads();
+    cap = cap_s;
+  }
+  for (uint32_t i = gl; i < cap; i += G) {
     sk[g][i] = i < n ? c_col[s + i] : EMPTY_KEY;
     sv[g][i] = i < n ? c_val[s + i] : T(0);
   }
   __syncthreads();
-  for (uint32_t k = 2; k <= CAP; k <<= 1) {
+  for (uint32_t k = 2; k <= cap; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = gl; i < CAP; i += G) {
-        const uint32_t l = i ^ j;
-        if (l > i) {
-          const uint32_t ki = sk[g][i], kl = sk[g][l];
-          const bool up = (i & k) == 0;
-          if ((ki > kl) == up) {
-            sk[g][i] = kl;
-            sk[g][l] = ki;
-            const T t = sv[g][i];
-            sv[g][i] = sv[g][l];
-            sv[g][l] = t;
-          }
+      for (uint32_t p = gl; p < cap / 2; p += G) {
+        const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
+        const uint32_t ki = sk[g][i], kl = sk[g][l];
+        const bool up = (i & k) == 0;
+        if ((ki > kl) == up) {
+          sk[g][i] = kl;
+          sk[g][l] = ki;
+          const T t = sv[g][i];
+          sv[g][i] = sv[g][l];
+          sv[g][l] = t;
         }
       }
       __syncthreads();
