@@ -821,7 +821,15 @@ constexpr int PIECE_U1 = SPAM_PIECE_U1;  // ... and in pass 1 (column loads only
 #ifndef SPAM_FLAT_EARLY
 #define SPAM_FLAT_EARLY 1
 #endif
-constexpr bool FLAT_EARLY = SPAM_FLAT_EARLY != 0;  // pass 1: first short-segment round in flight during the piece rounds
+constexpr bool FLAT_EARLY = SPAM_FLAT_EARLY != 0;
+#ifndef SPAM_TICKET
+#define SPAM_TICKET 1
+#endif
+constexpr bool TICKETS = SPAM_TICKET != 0;
+#ifndef SPAM_TICKET_FROM_PASS
+#define SPAM_TICKET_FROM_PASS 2
+#endif
+constexpr int TICKET_FROM_PASS = SPAM_TICKET_FROM_PASS;  // numeric heavy kernel: piece rounds of the shared head handed out by LDS ticket  // pass 1: first short-segment round in flight during the piece rounds
 
 struct RankWord {  // one bitmap word of the group's column span
   uint32_t prefix;  // entries of the group in lower words (valid after the prefix step)
@@ -943,6 +951,76 @@ __device__ __forceinline__ void long_pieces(uint32_t lo, uint32_t len, T av, uin
   }
 }
 
+// The same for the SHARED entries with the rounds handed out dynamically: all wavefronts number the pieces of the long
+// segments through identically, and a wavefront that is ready for more work takes the next round of PU consecutive
+// pieces with an LDS ticket (the passes of an item end when its slowest wavefront does, and with a fixed share per
+// wavefront that one takes 1.24x the mean: the spread comes from the memory round trips, not from the piece counts).
+// The PU pieces of a round lie in a handful of neighbouring segments, so their search is zero to two halvings.
+template <class T, int PASS>
+__device__ __forceinline__ void ticket_pieces(uint32_t lo, uint32_t len, T av, uint32_t* ticket,
+                                              const uint32_t* __restrict__ b_col, const T* __restrict__ b_val, uint32_t c0,
+                                              uint32_t cspan, RankWord* words, T* vals) {
+  const uint32_t lane = threadIdx.x & 63;
+  constexpr int PU = PASS <= 1 ? PIECE_U1 : PIECE_U;
+  const uint32_t np = len >= LONG_SEG ? (len + 63) >> 6 : 0u;  // pieces of this lane's segment
+  const uint32_t inc = wave_incl_scan_u32(np);
+  const uint32_t st = inc - np;
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+  const uint32_t nrounds = (total + PU - 1) / PU;
+  auto grab = [&]() -> uint32_t {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(ticket, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  };
+  // descriptors of round r in the lanes 0 .. PU - 1: position, length and A's value of piece r * PU + lane
+  auto build = [&](uint32_t r, uint32_t& q0, uint32_t& n, T& a) {
+    const uint32_t g0 = r * PU, g1 = (g0 + PU - 1 < total ? g0 + PU - 1 : total - 1);
+    const uint32_t g = g0 + lane < total ? g0 + lane : total - 1;  // (lanes >= PU compute along, unused)
+    uint32_t slo = (uint32_t)__popcll(__ballot(st <= g0)) - 1u, shi = (uint32_t)__popcll(__ballot(st <= g1)) - 1u;
+    for (uint32_t span = shi - slo; span != 0; span >>= 1) {  // uniform trip count
+      const uint32_t mid = (slo + shi + 1) >> 1;
+      if (shfl_u32(st, mid) <= g)
+        slo = mid;
+      else
+        shi = mid - 1;
+    }
+    const uint32_t pp = (g - shfl_u32(st, slo)) * 64;  // first product of the piece inside its segment
+    q0 = shfl_u32(lo, slo) + pp;
+    n = shfl_u32(len, slo) - pp;
+    a = PASS == 2 ? shfl_val(av, slo) : T(0);
+    if (g0 + lane >= total) n = 0;
+  };
+  uint32_t r = grab();
+  uint32_t q0 = 0, n = 0;
+  T a = T(0);
+  if (r < nrounds) build(r, q0, n, a);
+  while (r < nrounds) {
+    uint32_t cols[PU];
+    T prods[PU], sa[PU];
+#pragma unroll
+    for (int j = 0; j < PU; ++j) {
+      const uint32_t qj = (uint32_t)__builtin_amdgcn_readlane((int)q0, j);
+      const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n, j);
+      sa[j] = PASS == 2 ? readlane_val(a, (uint32_t)j) : T(0);
+      cols[j] = no_col(c0);
+      prods[j] = T(0);
+      if (lane < nj) {
+        const uint64_t q = (uint64_t)qj + lane;
+        cols[j] = b_col[q];
+        if (PASS == 2) prods[j] = b_val[q];
+      }
+    }
+    // the next round's ticket and descriptors under this round's loads
+    r = grab();
+    if (r < nrounds) build(r, q0, n, a);
+    if (PASS == 2) {
+#pragma unroll
+      for (int j = 0; j < PU; ++j) prods[j] = sa[j] * prods[j];  // t * t1 (mul_hash.rs:154)
+    }
+    accumulate_round<T, PASS, PU>(cols, prods, c0, cspan, words, vals);
+  }
+}
+
 // The products of one wavefront's 64 segments (one per lane: positions [lo, lo + len) of B's arrays, value av).
 // shared = true: every wavefront of the workgroup holds the same 64 segments (the head of A's row): long ones are
 // dealt piecewise, a short one goes whole to wavefront lane mod NW.  shared = false: the segments are this wavefront's
@@ -954,7 +1032,7 @@ __device__ __forceinline__ void long_pieces(uint32_t lo, uint32_t len, T av, uin
 template <class T, int PASS>
 __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, bool shared, uint32_t nw, uint32_t wave,
                                               const uint32_t* __restrict__ b_col, const T* __restrict__ b_val, uint32_t c0,
-                                              uint32_t cspan, RankWord* words, T* vals) {
+                                              uint32_t cspan, RankWord* words, T* vals, uint32_t* ticket = nullptr) {
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t lmask = __ballot(len >= LONG_SEG);
   // this lane's short segment.  Of the shared entries a wavefront takes the short segments of the lanes wave, wave + nw,
@@ -1037,6 +1115,18 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
   constexpr bool EARLY = FLAT_EARLY && PASS <= 1;
   uint32_t slo0[WAVE_U], cols0[WAVE_U];
   T bv0[WAVE_U];
+  if (ticket) {  // (uniform) the wavefront's fixed share first, the ticketed rounds last: they even out what it took
+    if (EARLY && total) issue(0, slo0, cols0, bv0);
+    for (uint32_t base = EARLY ? 64 * WAVE_U : 0; base < total; base += 64 * WAVE_U) {
+      uint32_t slo[WAVE_U], cols[WAVE_U];
+      T bv[WAVE_U];
+      issue(base, slo, cols, bv);
+      finish(slo, cols, bv);
+    }
+    if (lmask) ticket_pieces<T, PASS>(lo, len, av, ticket, b_col, b_val, c0, cspan, words, vals);
+    if (EARLY && total) finish(slo0, cols0, bv0);
+    return;
+  }
   if (EARLY && total) issue(0, slo0, cols0, bv0);
   if (lmask) long_pieces<T, PASS>(lo, len, av, shared ? nw : 1u, wave, b_col, b_val, c0, cspan, words, vals);
   if (EARLY && total) finish(slo0, cols0, bv0);
@@ -1386,6 +1476,7 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
   __shared__ __attribute__((aligned(16))) unsigned char region[REGION];
   __shared__ uint32_t wsum[NW + 1];
   __shared__ uint32_t run_s;
+  __shared__ uint32_t tick[2];  // round tickets of the two passes (SPAM_TICKET)
   RankWord* words = (RankWord*)region;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is uniform over a wavefront, and everything derived
@@ -1399,7 +1490,7 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
   unsigned long long t0 = 0;
   const bool timing = (dbg & 32) && threadIdx.x == 0;
   for (int i = threadIdx.x; i < (int)(REGION / 16); i += TPB) ((u32x4*)region)[i] = (u32x4)(0u);
-  if (threadIdx.x == 0) run_s = atomicAdd(queue, ITEM_RUN);
+  if (threadIdx.x == 0) run_s = atomicAdd(queue, ITEM_RUN), tick[0] = 0, tick[1] = 0;
   __syncthreads();
   // the workgroup's item sequence: runs of ITEM_RUN consecutive queue positions; `pos` walks the current run
   uint32_t run_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_s), run_next = 0xFFFFFFFFu, pos = 0;
@@ -1461,7 +1552,8 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
     // ---- both passes over the item's products: every wavefront on its own ------------------------------------
     auto all_products = [&](auto pass_tag) {
       constexpr int PASS = decltype(pass_tag)::value;
-      wave_products<T, PASS>(los_c, lens_c, as_c, true, NW, wave, b_col, b_val, c0, cspan, words, vals);
+      constexpr bool TK = TICKETS && PASS >= TICKET_FROM_PASS;
+      if (!TK) wave_products<T, PASS>(los_c, lens_c, as_c, true, NW, wave, b_col, b_val, c0, cspan, words, vals);
       if (it_c.n_a <= (uint32_t)(64 + TPB)) {
         if (it_c.n_a > 64)  // (uniform)
           wave_products<T, PASS>(loo_c, leno_c, ao_c, false, NW, wave, b_col, b_val, c0, cspan, words, vals);
@@ -1469,6 +1561,8 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
         streamed_products<T, PASS, USE_BPOS, NW>(a_col, a_val, it_c.a_start, it_c.n_a, j0, j1, wave, b_rp, b_col, b_val, bpos,
                                                  rows_b, c0, cspan, words, vals);
       }
+      if (TK)  // the shared head last, its piece rounds by ticket
+        wave_products<T, PASS>(los_c, lens_c, as_c, true, NW, wave, b_col, b_val, c0, cspan, words, vals, &tick[PASS - 1]);
     };
     all_products(std::integral_constant<int, 1>{});
     if (timing) {
@@ -1566,6 +1660,7 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
       }
     }
     if (pos == 0 && threadIdx.x == 0) run_s = claimed;
+    if (TICKETS && threadIdx.x == 0) tick[0] = 0, tick[1] = 0;  // (both passes are over; the next item starts behind the barrier)
     if (timing) {
       const unsigned long long t1 = clock64();
       wg_stat[6] += t1 - t0;
