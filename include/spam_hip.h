@@ -207,7 +207,7 @@ int spam_spgemm_dev(const spam_csr* a, const spam_csr* b, int sort_rows, spam_cs
  * all-gather of the ranks' row shards, which is the HOST's step: exchange the three arrays of spam_csr_device_ptrs
  * with RCCL — INTEGRATION.md shows the grouped ncclSend / ncclRecv sequence — and wrap the result with
  * spam_csr_from_device).  *c_block = the block of C (NULL when the block has no rows); C stays row-sharded.
- * row_overhead: 2300 measured on MI355X (spam_rows_to_parts_weighted). */
+ * row_overhead: 4000 measured on MI355X (spam_rows_to_parts_weighted). */
 int spam_spgemm_rank_step(const spam_csr* a_full, const spam_csr* b_full, uint64_t rank, uint64_t world,
                           uint64_t row_overhead, int sort_rows, spam_csr** c_block, uint64_t* row_lo, uint64_t* row_hi,
                           spam_spgemm_stats* stats);
@@ -217,7 +217,7 @@ int spam_spgemm_rank_step(const spam_csr* a_full, const spam_csr* b_full, uint64
 int spam_rows_to_parts(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t* row_flops_out /* rows */,
                        uint64_t* rows_offset_out /* nparts+1 */);
 /* The same partition rule on F_i + row_overhead * [F_i > 0]: on the GPU a block of many light rows runs longer
- * than a block of few heavy rows with equal F (measured: a non-empty row costs about 2300 products). */
+ * than a block of few heavy rows with equal F (measured: a non-empty row costs about 4000 products; 2300 with the round-1 kernels). */
 int spam_rows_to_parts_weighted(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t row_overhead,
                                 uint64_t* rows_offset_out /* nparts+1 */);
 

@@ -578,11 +578,9 @@ __global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ 
       const uint32_t cp = (q == s) ? 0u : (b_col[q - 1] >> CW_SHIFT);
       for (uint32_t j = cp + 1; j <= cq; ++j) bpos[(uint64_t)j * rows_b + k] = (uint32_t)q;
     }
-    if (lane == 0) {
-      bpos[k] = (uint32_t)s;
-      const uint32_t cl = (e > s) ? (b_col[e - 1] >> CW_SHIFT) : 0u;
-      for (uint32_t j = cl + 1; j <= nchunks; ++j) bpos[(uint64_t)j * rows_b + k] = (uint32_t)e;
-    }
+    if (lane == 0) bpos[k] = (uint32_t)s;
+    const uint32_t cl = (e > s) ? (b_col[e - 1] >> CW_SHIFT) : 0u;  // (the chunks behind the row's last entry: all lanes)
+    for (uint32_t j = cl + 1 + lane; j <= nchunks; j += 64) bpos[(uint64_t)j * rows_b + k] = (uint32_t)e;
   }
 }
 
@@ -1218,8 +1216,8 @@ template <bool USE_BPOS, int TPB, int WIN_SHIFT_, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(TPB, WAVES_PER_SIMD) void sym_heavy_kernel(const uint32_t* __restrict__ a_col, const uint64_t* __restrict__ b_rp,
                                                        const uint32_t* __restrict__ b_col, const uint32_t* __restrict__ bpos,
                                                        uint32_t rows_b, const SymItem* __restrict__ items, uint32_t n_rows,
-                                                       uint32_t nwin, uint32_t nchunks, int cw_shift,
-                                                       uint32_t* __restrict__ hcnt, uint32_t* __restrict__ queue) {
+                                                       uint32_t nwin, uint32_t n_giant, uint32_t sub_chunks, uint32_t nchunks,
+                                                       int cw_shift, uint32_t* __restrict__ hcnt, uint32_t* __restrict__ queue) {
   constexpr int NW = TPB / 64;
   constexpr uint32_t WIN_SHIFT = WIN_SHIFT_;
   constexpr uint32_t BM_WORDS = (1u << WIN_SHIFT) / 32;         // 128 KB for 2^20 columns
@@ -1227,8 +1225,12 @@ __global__ __launch_bounds__(TPB, WAVES_PER_SIMD) void sym_heavy_kernel(const ui
   __shared__ uint32_t run_s;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t n_items = n_rows * nwin;                       // (the host checks that this fits 32 bits)
   const uint32_t ch_per_win = (1u << WIN_SHIFT) >> cw_shift;    // numeric chunks per window
+  // the first n_giant rows of the list (the heaviest: a (row, window) item of theirs would keep one workgroup busy for
+  // milliseconds while the rest of the chip has run dry) are cut into sub-windows of sub_chunks chunks instead
+  const uint32_t nsub = (nchunks + sub_chunks - 1) / sub_chunks;
+  const uint32_t n_giant_items = n_giant * nsub;
+  const uint32_t n_items = n_giant_items + (n_rows - n_giant) * nwin;  // (the host checks that this fits 32 bits)
   const uint32_t cwords = (1u << cw_shift) >> 5;                // bitmap words per chunk
   for (int i = threadIdx.x; i < (int)(BM_WORDS / 4); i += TPB) ((u32x4*)bm)[i] = (u32x4)(0u);
   if (threadIdx.x == 0) run_s = atomicAdd(queue, ITEM_RUN);
@@ -1237,7 +1239,7 @@ __global__ __launch_bounds__(TPB, WAVES_PER_SIMD) void sym_heavy_kernel(const ui
   __syncthreads();
   struct Cur {
     uint64_t a_start;
-    uint32_t n_a, hrow, win, live;
+    uint32_t n_a, hrow, j0, j1, live;  // [j0, j1): the item's chunks
   };
   auto item_index = [&](uint32_t ahead) -> uint32_t {  // queue position of the item `ahead` steps after the current one
     const uint32_t q = pos + ahead;
@@ -1245,11 +1247,20 @@ __global__ __launch_bounds__(TPB, WAVES_PER_SIMD) void sym_heavy_kernel(const ui
     return run_next < n_items ? run_next + (q - ITEM_RUN) : 0xFFFFFFFFu;  // (ahead <= 3: the next run is known from pos 1 on)
   };
   auto load_item = [&](uint32_t idx, Cur& it) {
-    it.a_start = 0, it.n_a = 0, it.hrow = 0, it.win = 0, it.live = 0;
+    it.a_start = 0, it.n_a = 0, it.hrow = 0, it.j0 = 0, it.j1 = 0, it.live = 0;
     if (idx < n_items) {
-      const uint32_t r = nwin == 1 ? idx : idx / nwin;
+      uint32_t r, j0, width;
+      if (idx < n_giant_items) {
+        r = idx / nsub;
+        j0 = (idx - r * nsub) * sub_chunks, width = sub_chunks;
+      } else {
+        const uint32_t i2 = idx - n_giant_items, r2 = nwin == 1 ? i2 : i2 / nwin;
+        r = n_giant + r2;
+        j0 = (i2 - r2 * nwin) * ch_per_win, width = ch_per_win;
+      }
       const SymItem si = items[r];  // uniform address: scalar loads
-      it.a_start = si.a_start, it.n_a = si.n_a, it.hrow = si.hrow, it.win = idx - r * nwin, it.live = 1;
+      it.a_start = si.a_start, it.n_a = si.n_a, it.hrow = si.hrow, it.live = 1;
+      it.j0 = j0, it.j1 = j0 + width < nchunks ? j0 + width : nchunks;
     }
   };
   auto fetch_entry = [&](const Cur& it, uint32_t& ks, uint32_t& ko) {
@@ -1259,8 +1270,7 @@ __global__ __launch_bounds__(TPB, WAVES_PER_SIMD) void sym_heavy_kernel(const ui
     if (it.n_a <= (uint32_t)(64 + TPB) && e < it.n_a) ko = a_col[it.a_start + e];
   };
   auto fetch_range = [&](const Cur& it, uint32_t k, uint32_t& lo, uint32_t& len) {
-    const uint32_t j0 = it.win * ch_per_win, j1 = j0 + ch_per_win < nchunks ? j0 + ch_per_win : nchunks;
-    b_range<USE_BPOS>(bpos, b_rp, rows_b, j0, j1, k, lo, len);
+    b_range<USE_BPOS>(bpos, b_rp, rows_b, it.j0, it.j1, k, lo, len);
   };
   Cur it_c, it_n, it_nn, it_n3;
   uint32_t ks_c, ks_n, ks_nn, los_c, lens_c, los_n, lens_n;  // shared entry: current / next / next-next item
@@ -1275,8 +1285,8 @@ __global__ __launch_bounds__(TPB, WAVES_PER_SIMD) void sym_heavy_kernel(const ui
   while (it_c.live) {
     unsigned int claimed = 0;
     if (pos == 0 && threadIdx.x == 0) claimed = atomicAdd(queue, ITEM_RUN);
-    const uint32_t j0 = it_c.win * ch_per_win, j1 = j0 + ch_per_win < nchunks ? j0 + ch_per_win : nchunks;
-    const uint32_t c0 = it_c.win << WIN_SHIFT, cspan = (j1 - j0) << cw_shift;
+    const uint32_t j0 = it_c.j0, j1 = it_c.j1;
+    const uint32_t c0 = j0 << cw_shift, cspan = (j1 - j0) << cw_shift;
     fetch_range(it_n, ks_n, los_n, lens_n);
     fetch_range(it_n, ko_n, loo_n, leno_n);
     load_item(item_index(3), it_n3);
@@ -2481,7 +2491,24 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
                          : b->cols <= (16ull << 18) ? 3 : b->cols <= (32ull << 19) ? 2 : 0;
     const int win_shift = sym_geom == 0 ? 20 : sym_geom == 3 ? 18 : 19;
     const uint64_t nwin = (b->cols + (1ull << win_shift) - 1) >> win_shift;  // bitmap windows per row
-    if ((uint64_t)p->n_heavy * nwin >= 0xFFFFFFFFull) return set_error(SPAM_E_UNSUPPORTED, "too many (heavy row, column window) pairs for the 32-bit work queue");
+    // rows that hold more than about 1/1024 of this call's products (at least 2^22; a power of two, so that they are the
+    // first buckets of the cost order) are cut finer, into sub-windows of 1/32 window: one (row, window) item of theirs
+    // would keep a workgroup busy for milliseconds after the rest of the chip has run dry — the rank blocks of a multi-GPU
+    // product that hold the hubs felt it (symbolic phase of block 0 of 8 at scale 20: 7.9 -> 5.7 ms); a single-GPU product
+    // of that size has enough other rows to hide them (threshold 2^25 there: a handful of rows)
+    uint32_t n_giant = 0;
+    int giant_log2 = 22;
+    while (giant_log2 < 62 && (1ull << giant_log2) < st.flops_f / 1024) ++giant_log2;
+    const uint32_t sub_chunks = std::max<uint32_t>(1u, ((1u << win_shift) >> p->cw_shift) / 32u);
+    if (p->use_bpos) {
+      uint32_t ends[64];
+      SPAM_HIP_TRY(hipMemcpyAsync(ends, otmp.p, sizeof ends, hipMemcpyDeviceToHost, s));  // bucket ends after the scatter
+      SPAM_HIP_TRY(hipStreamSynchronize(s));
+      n_giant = std::min<uint32_t>(ends[63 - giant_log2], p->n_heavy);
+    }
+    const uint64_t nsub = ((uint64_t)p->nchunks + sub_chunks - 1) / sub_chunks;
+    const uint64_t n_sitems = (uint64_t)n_giant * nsub + (uint64_t)(p->n_heavy - n_giant) * nwin;
+    if (n_sitems >= 0xFFFFFFFFull) return set_error(SPAM_E_UNSUPPORTED, "too many (heavy row, column window) pairs for the 32-bit work queue");
     DevBuf sitems;
     SPAM_TRY(sitems.alloc((uint64_t)p->n_heavy * sizeof(SymItem)));
     sym_items_kernel<<<(p->n_heavy + 255) / 256, 256, 0, s>>>(sym_order.as<uint32_t>(), p->n_heavy, a->row_ptr,
@@ -2493,11 +2520,10 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     int per_cu = 0;                                                                                                  \
     SPAM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, TPB_, 0));                              \
     if (per_cu < 1) per_cu = 1;                                                                                      \
-    const uint64_t n_sitems = (uint64_t)p->n_heavy * nwin;                                                           \
     const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_cu * device_cus(), (n_sitems + ITEM_RUN - 1) / ITEM_RUN)); \
     if (dbg_sym) fprintf(stderr, "[spam dbg] symbolic heavy: %d threads, 2^%d columns, %d workgroups per CU, grid %u\n", TPB_, WS_, per_cu, sgrid); \
     kern<<<sgrid, TPB_, 0, s>>>(a->col_idx, b->row_ptr, p->b_col, BPOS_ ? p->bpos.as<uint32_t>() : nullptr, (uint32_t)b->rows, \
-                                sitems.as<SymItem>(), p->n_heavy, (uint32_t)nwin, p->nchunks, p->cw_shift,          \
+                                sitems.as<SymItem>(), p->n_heavy, (uint32_t)nwin, n_giant, sub_chunks, p->nchunks, p->cw_shift, \
                                 p->hcnt.as<uint32_t>(), counts.as<uint32_t>() + 8);                                  \
   } while (0)
 #define SPAM_SYM_HEAVY(BPOS_)                                                                                        \

@@ -160,7 +160,7 @@ def rows_to_parts_host(row_flops: torch.Tensor, nparts: int) -> list[int]:
     return offs
 
 
-ROW_OVERHEAD_PRODUCTS = 2300  # measured on MI355X (scale-20 A*A): a non-empty row costs about as much as 2300 products
+ROW_OVERHEAD_PRODUCTS = 4000  # measured on MI355X (scale-20 A*A, round-2 kernels): a non-empty row costs about as much as 4000 products
 
 
 def balanced_row_blocks(row_flops, nparts: int, row_overhead: int = ROW_OVERHEAD_PRODUCTS) -> list[int]:

@@ -17,7 +17,7 @@ B = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, A.vals, True)
 from sparse_matrix_amd import dist as spdist
 flops, offs = B.rows_to_parts(B, P)
 if os.environ.get("WEIGHTED", "1") == "1":
-    offs = np.array(spdist.balanced_row_blocks(flops.astype(np.int64), P))
+    offs = np.array(spdist.balanced_row_blocks(flops.astype(np.int64), P, int(os.environ.get("ROW_OVERHEAD", spdist.ROW_OVERHEAD_PRODUCTS))))
 print("offsets", offs.tolist())
 tot = []
 for rep in range(2):
