@@ -167,6 +167,14 @@ int spam_spmv_plan_info(const spam_csr* a, uint64_t* hot_columns, double* hot_co
 int spam_spmv_sliced_info(const spam_csr* a, int* active, uint64_t* long_rows, uint64_t* nnz_long, uint64_t* table_slots,
                           uint64_t* lds_slots, double* cover_table, double* cover_single, double* ms_plain,
                           double* ms_sliced);
+/* The long rows of a sliced plan are kept in ROW-GROUP form unless SPAM_SPMV_RG=0 (spam_spmv_rg.hip): per part and
+ * group of up to 8191 rows one block whose entries are stored in table-slot order and whose y accumulators live in
+ * LDS.  *active = 1 when the handle's plan has that form; row groups, non-empty (part, group) blocks, accumulators
+ * (rows that would serialise LDS atomics get several), bytes of the entry stream one SpMV reads, bytes of HBM the
+ * form holds.  In this form f32 / f64 sums are accumulated by LDS atomics: results agree with the reference to
+ * rounding (1e-10 / 1e-5 bars) but are not bit-identical from run to run; i64 results are exact. */
+int spam_spmv_rg_info(const spam_csr* a, int* active, uint64_t* row_groups, uint64_t* blocks, uint64_t* accumulators,
+                      uint64_t* stream_bytes, uint64_t* plan_bytes);
 
 /* ---- SpGEMM: C = A B, two phases like mul_hash ----------------------------------------------
  * spam_spgemm_symbolic  = rows_to_threads' flop count (mul_hash.rs:39-50) + mul_hash_symbolic (:66-103)

@@ -81,6 +81,7 @@ SYMBOLS = {
     "spam_csr_values_changed": (C.c_int, [_P]),
     "spam_spmv_plan_info": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(C.c_double), C.POINTER(_U64)]),
     "spam_spmv_sliced_info": (C.c_int, [_P, C.POINTER(C.c_int)] + [C.POINTER(_U64)] * 4 + [C.POINTER(C.c_double)] * 4),
+    "spam_spmv_rg_info": (C.c_int, [_P, C.POINTER(C.c_int)] + [C.POINTER(_U64)] * 5),
     "spam_spgemm_symbolic": (C.c_int, [_P, _P, _PP, C.POINTER(_U64)]),
     "spam_spgemm_numeric_f64": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "spam_spgemm_numeric_f32": (C.c_int, [_P, C.c_int, _P, _P, _P]),

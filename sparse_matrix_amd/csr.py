@@ -158,6 +158,10 @@ class DeviceCsr:
         info["sliced"] = {"active": bool(act.value), "long_rows": u[0].value, "nnz_long": u[1].value,
                           "table_slots_per_xcd": u[2].value, "lds_slots": u[3].value, "cover_table": d[0].value,
                           "cover_single": d[1].value, "ms_plain": d[2].value, "ms_sliced": d[3].value}
+        g = [C.c_uint64() for _ in range(5)]
+        check(_lib.load().spam_spmv_rg_info(self._h, C.byref(act), *[C.byref(v) for v in g]))
+        info["sliced"]["row_groups"] = {"active": bool(act.value), "groups": g[0].value, "blocks": g[1].value,
+                                        "accumulators": g[2].value, "stream_bytes": g[3].value, "plan_bytes": g[4].value}
         return info
 
     def spmv(self, x: np.ndarray) -> np.ndarray:

@@ -63,6 +63,9 @@ struct SpmvKnobs {
   int long_min = 0;      // SPAM_SPMV_LONG       rows with at least this many entries go to the slabs (0: model)
   int tpb = 256, snpt = 8, wgs = 16, pipe = 1;  // SPAM_SPMV_SLICED_TPB / _NPT / _WGS, SPAM_SPMV_PIPE
   int prof = 0;          // SPAM_SPMV_PROF       1 in-kernel phase timers, 2 skip phase 2 (diagnostics, wrong results)
+  int rg = 1;            // SPAM_SPMV_RG         long rows of the sliced path in row-group form (LDS accumulators,
+                         //                      spam_spmv_rg.hip); 0: the tile form
+  RgKnobs rgk;           // SPAM_SPMV_RG_{EBLK,NT,K,ABITS}
 };
 
 struct SpmvPlan {
@@ -694,6 +697,11 @@ static SpmvKnobs read_knobs() {
   k.wgs = env_int("SPAM_SPMV_SLICED_WGS", 16);
   k.pipe = env_int("SPAM_SPMV_PIPE", 1);
   k.prof = env_int("SPAM_SPMV_PROF", 0);
+  k.rg = env_int("SPAM_SPMV_RG", 1);
+  k.rgk.eblk = env_int("SPAM_SPMV_RG_EBLK", k.rgk.eblk);
+  k.rgk.nt = env_int("SPAM_SPMV_RG_NT", k.rgk.nt);
+  k.rgk.k = env_int("SPAM_SPMV_RG_K", k.rgk.k);
+  k.rgk.acc_bits = env_int("SPAM_SPMV_RG_ABITS", 0);
   return k;
 }
 
@@ -729,11 +737,10 @@ static int bisect_threshold(const uint32_t* cnt, uint32_t cols, uint64_t kmax, h
 // =====================================================================================================
 // XCD-sliced SpMV
 // =====================================================================================================
-constexpr int NSLAB = 8;                      // one table slab per XCD of MI355X
-constexpr int NPART = NSLAB + 1;              // + the cold part: entries whose column is in no table (gathered from x)
+constexpr int NSLAB = SPMV_NSLAB;             // one table slab per XCD of MI355X
+constexpr int NPART = SPMV_NPART;             // + the cold part: entries whose column is in no table (gathered from x)
 constexpr uint32_t NO_DEST = 0xFFFFFFFFu;
-constexpr int HEAD_STRIDE = 64;               // u32 words between two queue heads: one 256-byte block each, so the
-                                              // eight XCDs' dequeue atomics do not serialise on one line
+constexpr int HEAD_STRIDE = SPMV_HEAD_STRIDE; // u32 words between two queue heads
 
 template <class T>
 struct SlabDesc {
@@ -778,6 +785,7 @@ struct SlicedPlan {
   uint8_t* slab = nullptr;        // u8[cols]: part of a column (NSLAB = cold)
   uint32_t* res32 = nullptr;      // u32[rows + 1]: entry offsets of the short rows inside the residual
   uint64_t* sbase_d = nullptr;    // u64[NPART]: first entry of every part inside scol / sval
+  RgPlan* rg = nullptr;           // the long rows in row-group form (then srow_ptr .. descs above stay null)
   int hot = 2, prof = 0, wgs = 16;  // knobs the launches need
   float ms_plain = 0, ms_sliced = 0;
 };
@@ -788,6 +796,7 @@ static void sliced_plan_free(SlicedPlan* q) {
                   q->code, q->slab, q->res32, q->sbase_d};
   for (void* p : ptrs)
     if (p) dev_free(p);
+  if (q->rg) rg_plan_free(q->rg);
   if (q->residual) {
     spam_csr* r = q->residual;
     if (r->spmv_plan) spmv_plan_free(r->spmv_plan);
@@ -1382,8 +1391,16 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   sliced_long_list_kernel<<<gr, 256, 0, s>>>(is_long.as<uint32_t>(), posl.as<uint64_t>(), rows, long_rows.as<uint32_t>());
   SPAM_CHECK_LAUNCH();
 
-  // -- slab CSRs over the long rows ------------------------------------------------------------------------
+  // -- the long rows: row-group form (spam_spmv_rg.hip) or slab CSRs ------------------------------------------
+  if (kn.rg) SPAM_TRY(rg_build<T>(a, slab.as<uint8_t>(), code.as<uint32_t>(), long_rows.as<uint32_t>(), nl, S, kn.rgk, s, &q->rg));
   DevBuf cnt8, sc64, srow, sbase_d;
+  DevBuf scol, sval, sfo, scarry, partial, xh, descs, heads;
+  SPAM_TRY(partial.alloc((uint64_t)NPART * nl * sizeof(T)));
+  SPAM_TRY(xh.alloc((uint64_t)NSLAB * S * sizeof(T)));
+  SPAM_TRY(heads.alloc(NPART * HEAD_STRIDE * 4));
+  SPAM_HIP_TRY(hipMemsetAsync(xh.p, 0, (uint64_t)NSLAB * S * sizeof(T), s));  // unused slots stay defined
+  SPAM_HIP_TRY(hipMemsetAsync(partial.p, 0, (uint64_t)NPART * nl * sizeof(T), s));  // a part without entries never writes
+  if (!q->rg) {
   SPAM_TRY(cnt8.alloc((uint64_t)NPART * nl * 4));
   SPAM_TRY(sc64.alloc(((uint64_t)nl + 1) * 8));
   SPAM_TRY(srow.alloc((uint64_t)NPART * (nl + 1) * 4));
@@ -1410,17 +1427,11 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   }
   q->total_tiles = tile_base[NPART];
   SPAM_HIP_TRY(hipMemcpyAsync(sbase_d.p, sbase, NPART * 8, hipMemcpyHostToDevice, s));
-  DevBuf scol, sval, sfo, scarry, partial, xh, descs, heads;
   SPAM_TRY(scol.alloc((sbase[NPART] + 4) * 4));
   SPAM_TRY(sval.alloc((sbase[NPART] + 4) * sizeof(T)));
   SPAM_TRY(sfo.alloc(((uint64_t)q->total_tiles + NPART) * 4));
   SPAM_TRY(scarry.alloc(((uint64_t)q->total_tiles + 1) * sizeof(T)));
-  SPAM_TRY(partial.alloc((uint64_t)NPART * nl * sizeof(T)));
-  SPAM_TRY(xh.alloc((uint64_t)NSLAB * S * sizeof(T)));
   SPAM_TRY(descs.alloc(NPART * sizeof(SlabDesc<T>)));
-  SPAM_TRY(heads.alloc(NPART * HEAD_STRIDE * 4));
-  SPAM_HIP_TRY(hipMemsetAsync(xh.p, 0, (uint64_t)NSLAB * S * sizeof(T), s));  // unused slots stay defined
-  SPAM_HIP_TRY(hipMemsetAsync(partial.p, 0, (uint64_t)NPART * nl * sizeof(T), s));  // a slab without entries never writes
   sliced_fill_kernel<T><<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, code.as<uint32_t>(), slab.as<uint8_t>(),
                                            long_rows.as<uint32_t>(), nl, srow.as<uint32_t>(), sbase_d.as<uint64_t>(),
                                            scol.as<uint32_t>(), sval.as<T>());
@@ -1442,6 +1453,8 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
     SPAM_CHECK_LAUNCH();
   }
   SPAM_HIP_TRY(hipMemcpyAsync(descs.p, hd, sizeof(hd), hipMemcpyHostToDevice, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));  // hd, sbase go out of scope
+  }  // !q->rg
 
   // -- residual CSR: the non-empty short rows, compacted ---------------------------------------------------------
   spam_csr* res = new (std::nothrow) spam_csr();
@@ -1483,7 +1496,7 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   q->slab = (uint8_t*)slab.release();
   q->res32 = (uint32_t*)res32.release();
   q->sbase_d = (uint64_t*)sbase_d.release();
-  SPAM_TRY(sliced_dispatch<T>(q, nullptr, s, &q->grid));
+  if (!q->rg) SPAM_TRY(sliced_dispatch<T>(q, nullptr, s, &q->grid));
   // the short rows' own hot-column table (analysed on the residual's histogram)
   res->spmv_plan = new (std::nothrow) SpmvPlan();  // only the hot-column part is used
   if (!res->spmv_plan) return set_error(SPAM_E_OOM, "host allocation failed");
@@ -1499,7 +1512,9 @@ template <class T>
 static int sliced_refresh_values(const spam_csr* a, SlicedPlan* q, hipStream_t s) {
   const uint32_t rows = (uint32_t)a->rows;
   const unsigned gw = (unsigned)(((uint64_t)q->nl * 64 + 255) / 256), gr = (unsigned)(((uint64_t)rows + 255) / 256);
-  if (q->nl) {
+  if (q->rg) {
+    SPAM_TRY(rg_refresh_values<T>(a, q->rg, s));
+  } else if (q->nl) {
     sliced_fill_kernel<T, true><<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->code, q->slab, q->long_rows,
                                                    q->nl, q->srow_ptr, q->sbase_d, q->scol, (T*)q->sval);
     SPAM_CHECK_LAUNCH();
@@ -1538,13 +1553,18 @@ static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, 
   SPAM_CHECK_LAUNCH();
   // (running the short rows beside the slab kernel on a second stream was measured 3 % slower than one after the other)
   SPAM_TRY(residual_run<T>(a, q, x, y, s));
-  SPAM_TRY(sliced_dispatch<T>(q, x, s, nullptr));
-  const uint32_t tile = (uint32_t)(q->tpb * q->npt);
-  uint32_t max_tiles = (q->total_tiles + NPART - 1);  // >= any part's tile count
-  sliced_fixup_kernel<T><<<dim3((max_tiles + 255) / 256, NPART), 256, 0, s>>>((const SlabDesc<T>*)q->descs, tile);
-  SPAM_CHECK_LAUNCH();
+  if (q->rg) {
+    SPAM_TRY(rg_run<T>(q->rg, (const T*)q->xh, q->S, x, (T*)q->partial, q->nl, q->heads, s));
+  } else {
+    SPAM_TRY(sliced_dispatch<T>(q, x, s, nullptr));
+    const uint32_t tile = (uint32_t)(q->tpb * q->npt);
+    uint32_t max_tiles = (q->total_tiles + NPART - 1);  // >= any part's tile count
+    sliced_fixup_kernel<T><<<dim3((max_tiles + 255) / 256, NPART), 256, 0, s>>>((const SlabDesc<T>*)q->descs, tile);
+    SPAM_CHECK_LAUNCH();
+  }
 
-  sliced_reduce_kernel<T><<<(q->nl + 255) / 256, 256, 0, s>>>((const T*)q->partial, q->long_rows, q->nl, y);
+  // the row-group form stores the partial sums by rank (rows by length), the tile form by compact long-row index
+  sliced_reduce_kernel<T><<<(q->nl + 255) / 256, 256, 0, s>>>((const T*)q->partial, q->rg ? q->rg->rank_rows : q->long_rows, q->nl, y);
   SPAM_CHECK_LAUNCH();
   return SPAM_OK;
 }
@@ -1803,6 +1823,22 @@ int spam_spmv_sliced_info(const spam_csr* a, int* active, uint64_t* long_rows, u
   if (cover_single) *cover_single = q ? q->cover_single : 0.0;
   if (ms_plain) *ms_plain = a->spmv_plan ? a->spmv_plan->ms_plain : 0.0;
   if (ms_sliced) *ms_sliced = a->spmv_plan ? a->spmv_plan->ms_sliced : 0.0;
+  return SPAM_OK;
+}
+
+int spam_spmv_rg_info(const spam_csr* a, int* active, uint64_t* row_groups, uint64_t* blocks, uint64_t* accumulators,
+                      uint64_t* stream_bytes, uint64_t* plan_bytes) {
+  clear_error();
+  if (!a) return set_error(SPAM_E_INVALID, "matrix is NULL");
+  const SlicedPlan* q = a->spmv_plan ? a->spmv_plan->sliced : nullptr;
+  const RgPlan* g = q ? q->rg : nullptr;
+  if (active) *active = g ? 1 : 0;
+  if (row_groups) *row_groups = g ? g->ng : 0;
+  if (blocks) *blocks = g ? g->nonempty_blocks : 0;
+  if (accumulators) *accumulators = g ? g->naccs : 0;
+  if (stream_bytes) *stream_bytes = g ? g->stream_bytes : 0;
+  if (plan_bytes)
+    *plan_bytes = g ? g->stream_bytes + g->padded * 4 + ((uint64_t)g->ng * NPART + 1) * 16 + ((uint64_t)g->ng + 1) * 8 + g->naccs * 4 : 0;
   return SPAM_OK;
 }
 
