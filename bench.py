@@ -240,7 +240,32 @@ def main():
         # its own XCD's slice), the rest and the short rows' misses pay the fabric rate.
         info = dA.spmv_plan_info()
         sl = info["sliced"]
-        if sl["active"]:
+        rg = sl.get("row_groups", {"active": False})
+        plan_mode = "xcd_sliced_row_groups" if sl["active"] and rg["active"] else "xcd_sliced" if sl["active"] else "plain"
+        if sl["active"] and rg["active"]:
+            # row-group form: every gather is served by L1 / the XCD's L2 except the cold part's; the step runs at the
+            # fabric's byte rate, so the model is a byte count: entry stream + pair sums written and read + one 128-byte
+            # line per cold entry + the table rebuild (x, column map, tables) + y (zero-fill, then ~a 64-byte sector per
+            # long row and the short rows' range once)
+            cold = sl["nnz_long"] * (1.0 - sl["cover_table"])
+            model_bytes = (rg["stream_bytes"] + 16 * rg["accumulators"] + 128 * cold + A.cols * 12 + 16 * sl["table_slots_per_xcd"] * 8
+                           + A.rows * 8 + sl["long_rows"] * 6 + A.rows * 8)
+            model_ms = model_bytes / 6.3e12 * 1e3
+            out["roofline"]["kernel"] = ("XCD-sliced SpMV, row-group form: sliced_build_tables + spmv_rg_kernel + "
+                                         "spmv_rg_reduce_kernel (whole step)")
+            out["roofline"]["byte_model"] = {"mode": plan_mode, "entry_stream_bytes": rg["stream_bytes"],
+                                             "pair_sums": rg["accumulators"], "cold_entries": int(cold),
+                                             "model_bytes": int(model_bytes), "fabric_rate_Bps": 6.3e12,
+                                             "bound_ms": round(model_ms, 4), "frac_of_bound": round(model_ms / kern_ms, 4),
+                                             "source": "profiles/r03_stream_read_microbench.txt (6.4-7.0 TB/s ticketed reads), "
+                                                       "MI355X_MICROARCH.md (HBM ~6.3 TB/s achievable)"}
+            out["config"]["spmv_plan"] = {"mode": plan_mode, "sliced_rows": sl["long_rows"], "sliced_entries": sl["nnz_long"],
+                                          "table_slots_per_xcd": sl["table_slots_per_xcd"],
+                                          "cover_8_tables": round(sl["cover_table"], 4), "cover_1_table": round(sl["cover_single"], 4),
+                                          "row_groups": rg["groups"], "blocks": rg["blocks"], "pair_sums": rg["accumulators"],
+                                          "entry_stream_bytes": rg["stream_bytes"], "plan_bytes": rg["plan_bytes"],
+                                          "prepare_ms_plain": round(sl["ms_plain"], 4), "prepare_ms_sliced": round(sl["ms_sliced"], 4)}
+        elif sl["active"]:
             hits = sl["cover_table"] * sl["nnz_long"]
             model_ms = max(nbytes / 5.8e12, hits / 230e9 + (sl["nnz_long"] - hits) / 52e9) * 1e3
             out["roofline"]["kernel"] = ("XCD-sliced SpMV: sliced_build_tables + spmv_short_rows + spmv_sliced_pipe_kernel "
@@ -262,8 +287,8 @@ def main():
             out["config"]["spmv_plan"] = {"mode": "plain", "hot_columns": info["hot_columns"]}
         # HBM/fabric bytes per launch come from a separate rocprofv3 --pmc run (tools/prof_bench.sh), never from this
         # process; they are printed only when that run was taken on these kernel sources, this workload and this plan
-        tr, src = verified_traffic("spmv_pmc_latest.json", ("spam_spmv.hip",),
-                                   {"rows": A.rows, "nnz": A.nnz, "plan": "xcd_sliced" if sl["active"] else "plain"})
+        tr, src = verified_traffic("spmv_pmc_latest.json", ("spam_spmv.hip", "spam_spmv_rg.hip"),
+                                   {"rows": A.rows, "nnz": A.nnz, "plan": plan_mode})
         out["roofline"]["traffic"] = tr
         out["roofline"]["traffic_source"] = src
         log(f"[spmv] {ms_per_step:.4f} ms/step wall, {kern_ms:.4f} ms device, {achieved:.0f} GB/s "
@@ -321,7 +346,8 @@ def main():
                                         "effective_GB_per_s": round(b5 / (ms5 * 1e-3) / 1e9, 1),
                                         "frac_of_hbm_peak": round(b5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                         "algorithmic_bytes": b5,
-                                        "plan": "xcd_sliced" if d5.spmv_plan_info()["sliced"]["active"] else "plain"}
+                                        "plan": ("xcd_sliced_row_groups" if d5.spmv_plan_info()["sliced"]["row_groups"]["active"] else "xcd_sliced")
+                                        if d5.spmv_plan_info()["sliced"]["active"] else "plain"}
             log(f"[spmv f32 power-law] {ms5:.4f} ms/step, {b5 / (ms5 * 1e-3) / 1e9:.0f} GB/s")
             del d5, A5, x5, y5
             torch.cuda.empty_cache()

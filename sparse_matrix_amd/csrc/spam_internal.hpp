@@ -129,33 +129,39 @@ constexpr int SPMV_HEAD_STRIDE = 64;        // u32 words between two queue heads
 
 // ---- SpMV, row-group form of the sliced path's long rows (spam_spmv_rg.hip) ------------------------------------------
 struct RgKnobs {
-  int eblk = 100000;  // SPAM_SPMV_RG_EBLK   entries of a (part, row group) block aimed at
+  int eblk = 150000;  // SPAM_SPMV_RG_EBLK   entries of a (part, row group) block aimed at
   int nt = 512;       // SPAM_SPMV_RG_NT     threads per workgroup (256 / 512 / 1024)
   int k = 4;          // SPAM_SPMV_RG_K      chunks a wavefront keeps in flight
   int acc_bits = 0;   // SPAM_SPMV_RG_ABITS  cap on the accumulator bits of an entry word (0: as many as fit, at most 13)
+  int fold_short = 1; // SPAM_SPMV_RG_SHORT  the short rows as blocks of the same kernel (0: spmv_short_rows_kernel)
+  int order_min = 32; // SPAM_SPMV_RG_ORDER  rows with fewer entries are ranked in row order (coalesced y writes), longer ones by length
 };
 struct RgPlan {
-  uint32_t ng = 0, abits = 0, lds_bytes = 0;
+  uint32_t ng = 0, abits = 0, lds_bytes = 0, nl = 0, ntiles = 0;
+  uint32_t ngs = 0, ns = 0;         // short-row blocks (0: no short rows, or they keep their own kernel)
   int nt = 512, k = 4;
   unsigned grid = 0;
-  uint64_t stream_bytes = 0, entries = 0, padded = 0, naccs = 0, nonempty_blocks = 0;
+  uint64_t stream_bytes = 0, entries = 0, padded = 0, naccs = 0, npairs = 0, nonempty_blocks = 0;
   unsigned char* stream = nullptr;  // the blocks' chunks, part-major
-  uint64_t* blk_off = nullptr;      // u64[NPART * ng + 1]: byte offset of every block in `stream`
-  uint64_t* pe = nullptr;           // u64[NPART * ng + 1]: padded entries before every block
-  uint32_t* grp_row = nullptr;      // u32[ng + 1]: first rank of every group
-  uint32_t* grp_sub = nullptr;      // u32[ng + 1]: first extra accumulator of every group
-  uint32_t* sub_head = nullptr;     // u32[naccs - nl]: head of every extra accumulator
-  uint32_t* rank_rows = nullptr;    // u32[nl]: row of every rank (partial sums are stored by rank)
+  void* blk = nullptr;              // RgBlk[NPART * ng + ngs + 1]: block descriptors
+  uint64_t* pe = nullptr;           // u64[blocks + 1]: padded entries before every block
+  uint32_t* sub_head = nullptr;     // u32[naccs - npairs]: head of every extra accumulator
+  uint32_t* rank_rows = nullptr;    // u32[nl]: row of every rank
+  uint16_t* mask_rank = nullptr;    // u16[nl]: parts in which the row of a rank has a pair
+  void* tiles = nullptr;            // RgTile[ntiles]: 64 ranks of one group each
+  uint64_t* grp_cp = nullptr;       // u64[ng][NPART]: first pair of every (group, part) block in cp
+  void* cp = nullptr;               // T[npairs]: the pair sums of one SpMV
   uint32_t* vsrc = nullptr;         // u32[padded]: source entry of every value position (spam_csr_values_changed)
 };
 void rg_plan_free(RgPlan* g);
 // *out stays null when the matrix does not qualify (the caller then builds the tile form)
 template <class T>
 int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const uint32_t* long_rows, uint32_t nl, uint32_t S,
-             const RgKnobs& kn, hipStream_t s, RgPlan** out);
+             const spam_csr* res, uint32_t ns, const RgKnobs& kn, hipStream_t s, RgPlan** out);
 template <class T>
-int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, T* partial, uint32_t nl, uint32_t* queue, hipStream_t s);
+int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, uint32_t* queue, T* y, const uint32_t* short_rows,
+           hipStream_t s);
 template <class T>
-int rg_refresh_values(const spam_csr* a, RgPlan* g, hipStream_t s);
+int rg_refresh_values(const spam_csr* a, const spam_csr* res, RgPlan* g, hipStream_t s);
 
 }  // namespace spam

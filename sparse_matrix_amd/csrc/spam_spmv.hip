@@ -702,6 +702,8 @@ static SpmvKnobs read_knobs() {
   k.rgk.nt = env_int("SPAM_SPMV_RG_NT", k.rgk.nt);
   k.rgk.k = env_int("SPAM_SPMV_RG_K", k.rgk.k);
   k.rgk.acc_bits = env_int("SPAM_SPMV_RG_ABITS", 0);
+  k.rgk.fold_short = env_int("SPAM_SPMV_RG_SHORT", 1);
+  k.rgk.order_min = env_int("SPAM_SPMV_RG_ORDER", k.rgk.order_min);
   return k;
 }
 
@@ -1055,7 +1057,7 @@ __global__ void sliced_build_tables_kernel(const T* __restrict__ x, const uint32
                                            T* __restrict__ xh, uint32_t* __restrict__ heads, T* __restrict__ y,
                                            uint32_t rows) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < NPART) heads[i * HEAD_STRIDE] = 0;
+  if (i <= NPART) heads[i * HEAD_STRIDE] = 0;
   if (i < rows) y[i] = T(0);
   if (i >= cols) return;
   const uint32_t d = dest[i];
@@ -1340,7 +1342,9 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
     const double miss = std::max(0.05, 1.0 - cover_single);
     int lm = (int)std::ceil(1.8 / miss);
     lm = std::min(64, std::max(2, lm));
-    q->long_min = (uint32_t)(kn.long_min > 0 ? kn.long_min : lm);
+    // the row-group form keeps one accumulator per (row, part) pair that exists, so even one-entry rows are cheaper
+    // sliced (12 B entry + 16 B pair) than gathered from x past the tables (a 128-byte line per miss)
+    q->long_min = (uint32_t)(kn.long_min > 0 ? kn.long_min : (kn.rg ? 1 : lm));
   }
 
   DevBuf f0, f1, p0, p1, tmp, code, slab, dest;
@@ -1391,15 +1395,39 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   sliced_long_list_kernel<<<gr, 256, 0, s>>>(is_long.as<uint32_t>(), posl.as<uint64_t>(), rows, long_rows.as<uint32_t>());
   SPAM_CHECK_LAUNCH();
 
+  // -- residual CSR: the non-empty short rows, compacted ---------------------------------------------------------
+  spam_csr* res = new (std::nothrow) spam_csr();
+  if (!res) return set_error(SPAM_E_OOM, "host allocation failed");
+  q->residual = res;
+  res->rows = q->ns, res->cols = a->cols, res->nnz = nnz_res, res->dtype = a->dtype, res->is_sorted = a->is_sorted;
+  DevBuf short_rows;
+  {
+    DevBuf rc, rv, rp;
+    SPAM_TRY(rc.alloc((nnz_res + 4) * 4));
+    SPAM_TRY(rv.alloc((nnz_res + 4) * sizeof(T)));
+    SPAM_TRY(rp.alloc(((uint64_t)q->ns + 1) * 4));
+    SPAM_TRY(short_rows.alloc(((uint64_t)q->ns + 1) * 4));
+    sliced_residual_fill_kernel<T><<<gr, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->long_min,
+                                                      res32.as<uint32_t>(), rows, rc.as<uint32_t>(), rv.as<T>());
+    SPAM_CHECK_LAUNCH();
+    sliced_short_list_kernel<<<(unsigned)(((uint64_t)rows + 1 + 255) / 256), 256, 0, s>>>(
+        is_short.as<uint32_t>(), poss.as<uint64_t>(), res32.as<uint32_t>(), rows, q->ns, short_rows.as<uint32_t>(),
+        rp.as<uint32_t>());
+    SPAM_CHECK_LAUNCH();
+    res->row_ptr32 = (uint32_t*)rp.release();
+    res->col_idx = (uint32_t*)rc.release();
+    res->vals = rv.release();
+  }
   // -- the long rows: row-group form (spam_spmv_rg.hip) or slab CSRs ------------------------------------------
-  if (kn.rg) SPAM_TRY(rg_build<T>(a, slab.as<uint8_t>(), code.as<uint32_t>(), long_rows.as<uint32_t>(), nl, S, kn.rgk, s, &q->rg));
+  if (kn.rg)
+    SPAM_TRY(rg_build<T>(a, slab.as<uint8_t>(), code.as<uint32_t>(), long_rows.as<uint32_t>(), nl, S, res, q->ns, kn.rgk, s, &q->rg));
   DevBuf cnt8, sc64, srow, sbase_d;
   DevBuf scol, sval, sfo, scarry, partial, xh, descs, heads;
-  SPAM_TRY(partial.alloc((uint64_t)NPART * nl * sizeof(T)));
+  if (!q->rg) SPAM_TRY(partial.alloc((uint64_t)NPART * nl * sizeof(T)));  // (the row-group form keeps its pair sums)
   SPAM_TRY(xh.alloc((uint64_t)NSLAB * S * sizeof(T)));
-  SPAM_TRY(heads.alloc(NPART * HEAD_STRIDE * 4));
+  SPAM_TRY(heads.alloc((NPART + 1) * HEAD_STRIDE * 4));  // + the short-row queue of the row-group form
   SPAM_HIP_TRY(hipMemsetAsync(xh.p, 0, (uint64_t)NSLAB * S * sizeof(T), s));  // unused slots stay defined
-  SPAM_HIP_TRY(hipMemsetAsync(partial.p, 0, (uint64_t)NPART * nl * sizeof(T), s));  // a part without entries never writes
+  if (!q->rg) SPAM_HIP_TRY(hipMemsetAsync(partial.p, 0, (uint64_t)NPART * nl * sizeof(T), s));  // a part without entries never writes
   if (!q->rg) {
   SPAM_TRY(cnt8.alloc((uint64_t)NPART * nl * 4));
   SPAM_TRY(sc64.alloc(((uint64_t)nl + 1) * 8));
@@ -1456,29 +1484,6 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   SPAM_HIP_TRY(hipStreamSynchronize(s));  // hd, sbase go out of scope
   }  // !q->rg
 
-  // -- residual CSR: the non-empty short rows, compacted ---------------------------------------------------------
-  spam_csr* res = new (std::nothrow) spam_csr();
-  if (!res) return set_error(SPAM_E_OOM, "host allocation failed");
-  q->residual = res;
-  res->rows = q->ns, res->cols = a->cols, res->nnz = nnz_res, res->dtype = a->dtype, res->is_sorted = a->is_sorted;
-  DevBuf short_rows;
-  {
-    DevBuf rc, rv, rp;
-    SPAM_TRY(rc.alloc((nnz_res + 4) * 4));
-    SPAM_TRY(rv.alloc((nnz_res + 4) * sizeof(T)));
-    SPAM_TRY(rp.alloc(((uint64_t)q->ns + 1) * 4));
-    SPAM_TRY(short_rows.alloc(((uint64_t)q->ns + 1) * 4));
-    sliced_residual_fill_kernel<T><<<gr, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->long_min,
-                                                      res32.as<uint32_t>(), rows, rc.as<uint32_t>(), rv.as<T>());
-    SPAM_CHECK_LAUNCH();
-    sliced_short_list_kernel<<<(unsigned)(((uint64_t)rows + 1 + 255) / 256), 256, 0, s>>>(
-        is_short.as<uint32_t>(), poss.as<uint64_t>(), res32.as<uint32_t>(), rows, q->ns, short_rows.as<uint32_t>(),
-        rp.as<uint32_t>());
-    SPAM_CHECK_LAUNCH();
-    res->row_ptr32 = (uint32_t*)rp.release();
-    res->col_idx = (uint32_t*)rc.release();
-    res->vals = rv.release();
-  }
   SPAM_HIP_TRY(hipStreamSynchronize(s));  // host-side descriptor arrays and temporaries go out of scope
   q->dest = (uint32_t*)dest.release();
   q->xh = xh.release();
@@ -1497,10 +1502,12 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   q->res32 = (uint32_t*)res32.release();
   q->sbase_d = (uint64_t*)sbase_d.release();
   if (!q->rg) SPAM_TRY(sliced_dispatch<T>(q, nullptr, s, &q->grid));
-  // the short rows' own hot-column table (analysed on the residual's histogram)
-  res->spmv_plan = new (std::nothrow) SpmvPlan();  // only the hot-column part is used
-  if (!res->spmv_plan) return set_error(SPAM_E_OOM, "host allocation failed");
-  SPAM_TRY(spmv_hot_analyse<T>(res, res->spmv_plan, kn.hot_kb, s));
+  if (!(q->rg && q->rg->ngs)) {  // (in row-group form the short rows are blocks of the same kernel)
+    // the short rows' own hot-column table (analysed on the residual's histogram)
+    res->spmv_plan = new (std::nothrow) SpmvPlan();  // only the hot-column part is used
+    if (!res->spmv_plan) return set_error(SPAM_E_OOM, "host allocation failed");
+    SPAM_TRY(spmv_hot_analyse<T>(res, res->spmv_plan, kn.hot_kb, s));
+  }
   guard.q = nullptr;
   *out = q;
   return SPAM_OK;
@@ -1513,7 +1520,10 @@ static int sliced_refresh_values(const spam_csr* a, SlicedPlan* q, hipStream_t s
   const uint32_t rows = (uint32_t)a->rows;
   const unsigned gw = (unsigned)(((uint64_t)q->nl * 64 + 255) / 256), gr = (unsigned)(((uint64_t)rows + 255) / 256);
   if (q->rg) {
-    SPAM_TRY(rg_refresh_values<T>(a, q->rg, s));
+    sliced_residual_fill_kernel<T, true><<<gr, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->long_min, q->res32, rows,
+                                                            q->residual->col_idx, (T*)q->residual->vals);
+    SPAM_CHECK_LAUNCH();
+    return rg_refresh_values<T>(a, q->residual, q->rg, s);  // (reads the residual's refreshed values)
   } else if (q->nl) {
     sliced_fill_kernel<T, true><<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->code, q->slab, q->long_rows,
                                                    q->nl, q->srow_ptr, q->sbase_d, q->scol, (T*)q->sval);
@@ -1552,9 +1562,9 @@ static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, 
   sliced_build_tables_kernel<T><<<(unsigned)(((uint64_t)std::max(cols, rows) + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
   SPAM_CHECK_LAUNCH();
   // (running the short rows beside the slab kernel on a second stream was measured 3 % slower than one after the other)
-  SPAM_TRY(residual_run<T>(a, q, x, y, s));
+  if (!(q->rg && q->rg->ngs)) SPAM_TRY(residual_run<T>(a, q, x, y, s));
   if (q->rg) {
-    SPAM_TRY(rg_run<T>(q->rg, (const T*)q->xh, q->S, x, (T*)q->partial, q->nl, q->heads, s));
+    return rg_run<T>(q->rg, (const T*)q->xh, q->S, x, q->heads, y, q->short_rows, s);  // (its own reduce inside)
   } else {
     SPAM_TRY(sliced_dispatch<T>(q, x, s, nullptr));
     const uint32_t tile = (uint32_t)(q->tpb * q->npt);
@@ -1563,8 +1573,7 @@ static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, 
     SPAM_CHECK_LAUNCH();
   }
 
-  // the row-group form stores the partial sums by rank (rows by length), the tile form by compact long-row index
-  sliced_reduce_kernel<T><<<(q->nl + 255) / 256, 256, 0, s>>>((const T*)q->partial, q->rg ? q->rg->rank_rows : q->long_rows, q->nl, y);
+  sliced_reduce_kernel<T><<<(q->nl + 255) / 256, 256, 0, s>>>((const T*)q->partial, q->long_rows, q->nl, y);
   SPAM_CHECK_LAUNCH();
   return SPAM_OK;
 }
@@ -1838,7 +1847,9 @@ int spam_spmv_rg_info(const spam_csr* a, int* active, uint64_t* row_groups, uint
   if (accumulators) *accumulators = g ? g->naccs : 0;
   if (stream_bytes) *stream_bytes = g ? g->stream_bytes : 0;
   if (plan_bytes)
-    *plan_bytes = g ? g->stream_bytes + g->padded * 4 + ((uint64_t)g->ng * NPART + 1) * 16 + ((uint64_t)g->ng + 1) * 8 + g->naccs * 4 : 0;
+    *plan_bytes = g ? g->stream_bytes + g->padded * 4 + ((uint64_t)g->ng * NPART + g->ngs + 1) * 48 + (uint64_t)g->ng * NPART * 8 +
+                            (uint64_t)g->ntiles * 32 + (uint64_t)g->nl * 6 + g->npairs * 8 + (g->naccs - g->npairs) * 4
+                      : 0;
   return SPAM_OK;
 }
 

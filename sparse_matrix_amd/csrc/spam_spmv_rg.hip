@@ -1,23 +1,26 @@
-// SpMV, XCD-sliced path, "row-group" form of the long rows (gfx950 only).
+// SpMV, XCD-sliced path, "row-group" form (gfx950 only).
 //
 // The XCD-sliced analysis (spam_spmv.hip) deals the most referenced columns over eight table slabs, one per XCD's L2,
-// and cuts every long row into nine PARTS: its entries in slab 0..7 and the cold rest.  The first form of that path
-// kept each part as a CSR over the long rows and summed rows tile by tile: the x gathers of a tile go to unrelated
+// and cuts every sliced row into nine PARTS: its entries in slab 0..7 and the cold rest.  The first form of that path
+// kept each part as a CSR over the sliced rows and summed rows tile by tile: the x gathers of a tile go to unrelated
 // table lines, every lane costs the L2 one request, and 245 G requests/s bound the kernel (0.78 ms for 154 M entries).
 //
-// This form turns the part around.  The long rows are ranked by length and cut into ROW GROUPS of at most 2^abits - 1
-// accumulators; a BLOCK is (part, row group):
-//   * the y accumulators of the group's rows live in LDS (8 bytes each: f64 for f32 / f64 values, u64 for i64);
+// This form turns the part around.  The sliced rows are ranked by length and cut into ROW GROUPS; a BLOCK is
+// (part, row group):
+//   * the block's accumulators live in LDS (8 bytes each: f64 for f32 / f64 values, u64 for i64), one per (row, part)
+//     PAIR that exists — a row without entries in the part has none, so short rows cost what they hold;
 //   * the block's entries are stored in TABLE-SLOT order, 256-entry chunks, each entry one 32-bit word
 //     (slot << abits | accumulator) and its value: a wave instruction gathers 64 consecutive slots — a handful of
 //     128-byte lines that the CU's L1 serves — and adds its products with LDS atomics (ds_add_f64 / ds_add_u64);
-//   * the group's partial sums go to partial[part][rank of the row], dense and coalesced (accumulator j of a group is
-//     the row of rank first + j), and sliced_reduce_kernel adds the nine parts into y[row of that rank].
-// Rows that would draw most lanes of a wave instruction to one LDS address get extra accumulators behind the group's
-// heads (an entry's accumulator is picked by its position in the row mod the count); they are folded into their head
-// before the partial is written.
-// Measured on the bench matrix (10 M x 10 M R-MAT, 153.7 M entries in 1.48 M long rows): 0.42 ms against 0.78 ms;
-// without the gathers the kernel takes the same time — what is left is the stream itself (12 bytes per entry).
+//   * the block stores its sums as one contiguous run of the pair array `cp` (pairs of a block in rank order);
+//   * spmv_rg_reduce_kernel, one wavefront per 64 ranks, finds a row's pair in every part from the row's part mask
+//     (position = tile base + ballot prefix), adds them in part order and writes y[row of that rank].
+// Rows that would draw most lanes of a wave instruction to one LDS address get extra accumulators behind the block's
+// heads (an entry picks one by its position in the row); they are folded into their head before the sums are stored.
+// Rows below the sliced-row threshold (none by default) join as a tenth kind of block: consecutive short rows, all
+// their entries unsliced in column order, gathered from x itself, results written straight to y.
+//
+// The kernel runs at the fabric's byte rate: what a change saves is the bytes it no longer moves.
 //
 // Sums of f32 / f64 values are accumulated by LDS atomics in an order that varies from run to run: results are
 // reproducible to rounding, not bit for bit (i64 results are exact and bit-identical).
@@ -36,6 +39,8 @@ constexpr uint32_t RG_NONE = 0xFFFFFFFFu;
 constexpr int RG_KEY_ACC_BITS = 14, RG_KEY_IDX_BITS = 32;
 constexpr int RG_KEY_BLK_SHIFT = RG_KEY_ACC_BITS + RG_KEY_IDX_BITS;  // 46
 constexpr uint32_t RG_MAX_SUB = 512;
+constexpr uint32_t RG_FULL_MASK = (1u << SPMV_NPART) - 1u;
+constexpr uint32_t RG_SHORT = (uint32_t)SPMV_NPART;  // queue / part number of the short-row blocks
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -68,17 +73,40 @@ __host__ __device__ __forceinline__ uint32_t rg_val_slot(uint32_t lane, uint32_t
   return sizeof(T) == 8 ? (k >> 1) * 128u + 2u * lane + (k & 1u) : 4u * lane + k;
 }
 
+// One (part, row group) block; blocks are stored part-major (b = part * ng + group), the short-row blocks behind them.
+struct RgBlk {
+  uint64_t off;      // byte offset of the block's first chunk in the stream
+  uint64_t cp0;      // first pair of the block in cp (short-row blocks: first short row)
+  uint32_t nchunks;  // 0: nothing to do
+  uint32_t nheads;   // pairs of the block = head accumulators (short-row blocks: rows)
+  uint32_t nsubs;    // extra accumulators behind the heads
+  uint32_t sub0;     // their heads: sub_head[sub0 ..)
+};
+static_assert(sizeof(RgBlk) == 32, "RgBlk layout");
+
+// 64 consecutive ranks of one group
+struct RgTile {
+  uint32_t row0;                // first rank
+  uint32_t grp;
+  uint16_t n;                   // ranks in the tile
+  uint16_t base[SPMV_NPART];    // pairs of the group's earlier tiles, per part
+  uint16_t pad[2];
+};
+static_assert(sizeof(RgTile) == 32, "RgTile layout");
+
 template <class T>
 struct RgArgs {
-  const uint64_t* blk_off;    // [NPART * ng + 1] byte offset of every block's first chunk (part-major)
-  const uint32_t* grp_row;    // [ng + 1] first rank of every group (its head accumulators are its rows, in rank order)
-  const uint32_t* grp_sub;    // [ng + 1] first extra accumulator of every group in sub_head
-  const uint32_t* sub_head;   // per extra accumulator: the head (local) it is folded into
+  const RgBlk* blk;
+  const uint32_t* sub_head;   // per extra accumulator: the head (block-local) it is folded into
   const unsigned char* stream;
   const T* base[SPMV_NPART];  // gather source of every part: the slab tables, x for the cold part
-  T* partial;                 // [NPART][nl]
-  uint32_t* queue;            // NPART heads, SPMV_HEAD_STRIDE words apart (reset by sliced_build_tables_kernel)
-  uint32_t ng, nl, abits;
+  T* cp;                      // the pair sums
+  uint32_t* queue;            // NPART + 1 heads, SPMV_HEAD_STRIDE words apart (reset by sliced_build_tables_kernel)
+  uint32_t ng, abits;
+  // short rows: block 9 * ng + gs holds short rows [cp0, cp0 + nheads), all their entries; y[short_rows[.]] directly
+  T* y;
+  const uint32_t* short_rows;
+  uint32_t ngs;
 };
 
 template <class T>
@@ -100,21 +128,21 @@ __device__ __forceinline__ void rg_load_vals(const unsigned char* qv, int lane, 
 // the waits (a cross-iteration software pipeline was measured no faster, and the compiler's register rotation made it
 // wait for the loads it had just issued).
 template <class T, int NT, int K, bool WIDE>
-__device__ __forceinline__ void rg_stream(const unsigned char* p0, uint64_t nchunks, int wave, int lane,
+__device__ __forceinline__ void rg_stream(const unsigned char* p0, uint32_t nchunks, int wave, int lane,
                                           const T RG_GLB* xg, typename RgAcc<T>::type* acc, uint32_t abits) {
   typedef RgAcc<T> A;
   constexpr int nw = NT / 64;
   constexpr uint32_t CB = rg_chunk_bytes<T>(WIDE);
   constexpr uint32_t VOFF = WIDE ? 1536u : 1024u;
   const uint32_t amask = (1u << abits) - 1u;
-  uint64_t c = (uint64_t)wave;
-  for (; c + (uint64_t)(K - 1) * nw < nchunks; c += (uint64_t)K * nw) {
+  uint32_t c = (uint32_t)wave;
+  for (; c + (uint32_t)(K - 1) * nw < nchunks; c += (uint32_t)K * nw) {
     u32x4 w[K];
     u32x2 a[K];
     T v[K][4], xv[K][4];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const unsigned char* q = p0 + (c + (uint64_t)k * nw) * CB;
+      const unsigned char* q = p0 + (uint64_t)(c + (uint32_t)k * nw) * CB;
       w[k] = __builtin_nontemporal_load((const u32x4*)(q + 16 * lane));
       if (WIDE) a[k] = __builtin_nontemporal_load((const u32x2*)(q + 1024 + 8 * lane));
       rg_load_vals<T>(q + VOFF, lane, v[k]);
@@ -143,7 +171,7 @@ __device__ __forceinline__ void rg_stream(const unsigned char* p0, uint64_t nchu
     }
   }
   for (; c < nchunks; c += nw) {
-    const unsigned char* q = p0 + c * CB;
+    const unsigned char* q = p0 + (uint64_t)c * CB;
     const u32x4 w = __builtin_nontemporal_load((const u32x4*)(q + 16 * lane));
     u32x2 a = {0u, 0u};
     if (WIDE) a = __builtin_nontemporal_load((const u32x2*)(q + 1024 + 8 * lane));
@@ -165,9 +193,10 @@ __device__ __forceinline__ void rg_stream(const unsigned char* p0, uint64_t nchu
   }
 }
 
-// Persistent workgroups.  A workgroup reads the XCD it runs on and serves that slab's queue, then the cold queue, then
-// whatever the other slabs have left (so nothing depends on the placement); one workgroup in four starts with the cold
-// queue, whose blocks wait for fabric round trips and overlap with the streaming of the others.
+// Persistent workgroups.  A workgroup reads the XCD it runs on and serves that slab's queue, then the cold queue, the
+// short rows, then whatever the other slabs have left (so nothing depends on the placement); one workgroup in four
+// starts with the cold queue and the short rows, whose blocks wait for fabric round trips and overlap with the
+// streaming of the others.
 template <class T, int NT, int K>
 __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
   typedef typename RgAcc<T>::type AccT;
@@ -180,83 +209,169 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
   int q = 0;
   for (;;) {
     uint32_t part;
-    if (cold_first) part = q == 0 ? (uint32_t)SPMV_NSLAB : q == 1 ? xcc : ((xcc + (uint32_t)(q - 1)) & 7u);
-    else part = q == 0 ? xcc : q == 1 ? (uint32_t)SPMV_NSLAB : ((xcc + (uint32_t)(q - 1)) & 7u);
+    if (cold_first) part = q == 0 ? (uint32_t)SPMV_NSLAB : q == 1 ? RG_SHORT : q == 2 ? xcc : ((xcc + (uint32_t)(q - 2)) & 7u);
+    else part = q == 0 ? xcc : q == 1 ? (uint32_t)SPMV_NSLAB : q == 2 ? RG_SHORT : ((xcc + (uint32_t)(q - 2)) & 7u);
     if (threadIdx.x == 0) s_blk = atomicAdd(P.queue + (uint64_t)SPMV_HEAD_STRIDE * part, 1u);
     __syncthreads();
-    const uint32_t g = s_blk;
+    const uint32_t g = __builtin_amdgcn_readfirstlane(s_blk);
     __syncthreads();
-    if (g >= P.ng) {
-      if (++q > SPMV_NSLAB) break;
+    const bool is_short = part == RG_SHORT;
+    if (g >= (is_short ? P.ngs : P.ng)) {
+      if (++q > SPMV_NSLAB + 1) break;
       continue;
     }
-    const uint64_t b = (uint64_t)part * P.ng + g;
-    const uint64_t o0 = P.blk_off[b], o1 = P.blk_off[b + 1];
-    if (o1 == o0) continue;  // no entry of this group in this part: its partial sums stay zero
-    const uint32_t r0 = P.grp_row[g], nrows = P.grp_row[g + 1] - r0;
-    const uint32_t s0 = P.grp_sub[g], nsubs = P.grp_sub[g + 1] - s0;
-    const uint32_t na = nrows + nsubs;
+    const RgBlk* bd = P.blk + ((uint64_t)part * P.ng + g);
+    const uint32_t nchunks = bd->nchunks;
+    if (nchunks == 0) continue;  // no entry of this group in this part (its pairs, if any, stay zero)
+    const uint64_t off = bd->off, cp0 = bd->cp0;
+    const uint32_t nheads = bd->nheads, nsubs = bd->nsubs, sub0 = bd->sub0;
+    const uint32_t na = nheads + nsubs;
     for (uint32_t i = threadIdx.x; i <= na; i += NT) acc[i] = AccT(0);  // [na] takes the padding entries
     __syncthreads();
-    if (part == (uint32_t)SPMV_NSLAB)
-      rg_stream<T, NT, K, true>(P.stream + o0, (o1 - o0) / rg_chunk_bytes<T>(true), wave, lane, (const T RG_GLB*)P.base[part],
-                                acc, P.abits);
+    if (part >= (uint32_t)SPMV_NSLAB)
+      rg_stream<T, NT, K, true>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[SPMV_NSLAB], acc, P.abits);
     else
-      rg_stream<T, NT, K, false>(P.stream + o0, (o1 - o0) / rg_chunk_bytes<T>(false), wave, lane,
-                                 (const T RG_GLB*)P.base[part], acc, P.abits);
+      rg_stream<T, NT, K, false>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc, P.abits);
     __syncthreads();
     if (nsubs) {  // uniform
-      for (uint32_t i = threadIdx.x; i < nsubs; i += NT) atomicAdd(&acc[P.sub_head[s0 + i]], acc[nrows + i]);
+      for (uint32_t i = threadIdx.x; i < nsubs; i += NT) atomicAdd(&acc[P.sub_head[sub0 + i]], acc[nheads + i]);
       __syncthreads();
     }
-    T* out = P.partial + (uint64_t)part * P.nl + r0;
-    for (uint32_t i = threadIdx.x; i < nrows; i += NT) out[i] = (T)acc[i];
+    if (is_short) {
+      const uint32_t* sr = P.short_rows + cp0;
+#pragma unroll 4
+      for (uint32_t i = threadIdx.x; i < nheads; i += NT) P.y[sr[i]] = (T)acc[i];
+    } else {
+      T* out = P.cp + cp0;
+      for (uint32_t i = threadIdx.x; i < nheads; i += NT) out[i] = (T)acc[i];
+    }
     __syncthreads();
   }
 }
 
-// ---- plan construction ------------------------------------------------------------------------------------------
-__global__ void rg_len_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ long_rows, uint32_t nl,
-                              uint32_t* __restrict__ len, uint32_t* __restrict__ key, uint32_t* __restrict__ idx) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nl) return;
-  const uint32_t r = long_rows[i];
-  const uint32_t l = row_ptr[r + 1] - row_ptr[r];
-  len[i] = l;
-  key[i] = ~l;  // ascending sort of ~len = descending lengths
-  idx[i] = i;
+// y[row of rank] = sum of the row's pairs, in part order.  One wavefront per tile of 64 ranks: a row's pair in part p is
+// the (tile base + number of earlier ranks of the tile with a pair in p)-th of block (p, group).
+template <class T>
+__global__ __launch_bounds__(256) void spmv_rg_reduce_kernel(const RgTile* __restrict__ tiles, uint32_t ntiles,
+                                                             const uint16_t* __restrict__ mask_rank,
+                                                             const uint32_t* __restrict__ rank_rows,
+                                                             const uint64_t* __restrict__ grp_cp, const T* __restrict__ cp,
+                                                             T* __restrict__ y) {
+  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (t >= ntiles) return;
+  const RgTile tl = tiles[t];
+  const bool act = lane < tl.n;
+  const uint32_t k = tl.row0 + lane;
+  const uint32_t m = act ? mask_rank[k] : 0u;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint64_t* gc = grp_cp + (uint64_t)tl.grp * SPMV_NPART;
+  T v[SPMV_NPART];
+#pragma unroll
+  for (int p = 0; p < SPMV_NPART; ++p) {
+    const bool has = (m >> p) & 1u;
+    const uint64_t bal = __ballot(has);
+    const uint64_t at = gc[p] + tl.base[p] + (uint64_t)__popcll(bal & lt);
+    v[p] = has ? cp[at] : T(0);
+  }
+  T s = v[0];
+#pragma unroll
+  for (int p = 1; p < SPMV_NPART; ++p) s += v[p];
+  if (act) y[rank_rows[k]] = s;
 }
 
-// One wavefront per long row: sort key (block | table slot or column | accumulator) and source position of every entry.
+// ---- plan construction ------------------------------------------------------------------------------------------
+// One wavefront per sliced row: length and the parts it has entries in.
+__global__ void rg_row_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                              const uint8_t* __restrict__ slab, const uint32_t* __restrict__ long_rows, uint32_t nl,
+                              uint32_t order_min, uint32_t* __restrict__ len, uint32_t* __restrict__ key,
+                              uint32_t* __restrict__ idx, uint16_t* __restrict__ mask) {
+  const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (w >= nl) return;
+  const uint32_t r = long_rows[w];
+  const uint32_t s = row_ptr[r], e = row_ptr[r + 1];
+  uint32_t m = 0;
+  for (uint32_t p = s + lane; p < e; p += 64) m |= 1u << slab[col[p]];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+  if (lane == 0) {
+    len[w] = e - s;
+    // ascending (stable) sort of ~len = descending lengths; rows below order_min entries all get one key and so keep
+    // their row order behind the longer ones: the reduce then writes neighbouring y entries from neighbouring lanes
+    key[w] = ~max(e - s, order_min - 1u);
+    idx[w] = (uint32_t)w;
+    mask[w] = (uint16_t)m;
+  }
+}
+__global__ void rg_rank_kernel(const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ idx_of_rank,
+                               const uint16_t* __restrict__ mask, const uint32_t* __restrict__ len, uint32_t nl,
+                               uint32_t* __restrict__ rank_rows, uint32_t* __restrict__ rank_of,
+                               uint16_t* __restrict__ mask_rank, uint32_t* __restrict__ len_rank) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nl) return;
+  const uint32_t i = idx_of_rank[k];
+  rank_rows[k] = long_rows[i];
+  rank_of[i] = k;
+  mask_rank[k] = mask[i];
+  len_rank[k] = len[i];
+}
+// One wavefront per tile: the head accumulator of every (rank, part) pair inside its block.
+__global__ void rg_hidx_kernel(const RgTile* __restrict__ tiles, uint32_t ntiles, const uint16_t* __restrict__ mask_rank,
+                               uint16_t* __restrict__ hidx) {
+  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (t >= ntiles) return;
+  const RgTile tl = tiles[t];
+  const bool act = lane < tl.n;
+  const uint32_t k = tl.row0 + lane;
+  const uint32_t m = act ? mask_rank[k] : 0u;
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int p = 0; p < SPMV_NPART; ++p) {
+    const uint64_t bal = __ballot((m >> p) & 1u);
+    if (act) hidx[(uint64_t)k * SPMV_NPART + p] = (uint16_t)(tl.base[p] + (uint32_t)__popcll(bal & lt));
+  }
+}
+
+// One wavefront per sliced row: sort key (block | table slot or column | accumulator) and source position of every entry.
 __global__ void rg_keys_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                const uint32_t* __restrict__ code, const uint8_t* __restrict__ slab,
                                const uint32_t* __restrict__ long_rows, uint32_t nl, const uint64_t* __restrict__ lofs,
-                               const uint32_t* __restrict__ row_grp, const uint32_t* __restrict__ row_acc,
-                               const uint32_t* __restrict__ row_sub, uint32_t ng, uint64_t* __restrict__ keys,
+                               const uint32_t* __restrict__ rank_of, const uint32_t* __restrict__ rk_grp,
+                               const uint32_t* __restrict__ rk_sub, const uint16_t* __restrict__ hidx,
+                               const RgBlk* __restrict__ blk, uint32_t ng, uint64_t* __restrict__ keys,
                                uint32_t* __restrict__ src) {
   const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t lane = threadIdx.x & 63;
   if (w >= nl) return;
   const uint32_t r = long_rows[w];
   const uint32_t s = row_ptr[r], e = row_ptr[r + 1];
-  const uint32_t g = row_grp[w], ra = row_acc[w];
-  const uint32_t head = ra & 0xFFFFu, nsub = ra >> 16;  // accumulators of the row: its head and nsub - 1 extra ones
-  const uint32_t sbase = nsub > 1 ? row_sub[w] : 0u;
+  const uint32_t k = rank_of[w];
+  const uint32_t g = rk_grp[k], rs = rk_sub[k];
+  const uint32_t nsub = rs >> 16, sofs = rs & 0xFFFFu;  // accumulators of the row in a block: its head and nsub - 1 extra
   const uint64_t o = lofs[w];
   for (uint32_t p = s + lane; p < e; p += 64) {
     const uint32_t c = col[p];
-    const uint64_t b = (uint64_t)slab[c] * ng + g;
+    const uint32_t part = slab[c];
+    const uint64_t b = (uint64_t)part * ng + g;
     const uint32_t sub = nsub > 1 ? (p - s) % nsub : 0u;
-    const uint32_t acc = sub ? sbase + sub - 1u : head;
+    const uint32_t acc = sub ? blk[b].nheads + sofs + sub - 1u : (uint32_t)hidx[(uint64_t)k * SPMV_NPART + part];
     keys[o + (p - s)] = (b << RG_KEY_BLK_SHIFT) | ((uint64_t)code[c] << RG_KEY_ACC_BITS) | (uint64_t)acc;
     src[o + (p - s)] = p;
   }
 }
 
-__global__ void rg_rank_rows_kernel(const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ idx_of_rank, uint32_t nl,
-                                    uint32_t* __restrict__ rank_rows) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < nl) rank_rows[k] = long_rows[idx_of_rank[k]];
+// One thread per short row (compact): its entries, unsliced, keyed by (short block, column).
+__global__ void rg_short_keys_kernel(const uint32_t* __restrict__ res_ptr, const uint32_t* __restrict__ res_col, uint32_t ns,
+                                     uint32_t srows, uint64_t first_blk, uint64_t out0, uint64_t* __restrict__ keys,
+                                     uint32_t* __restrict__ src) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const uint64_t b = first_blk + i / srows;
+  const uint32_t a = i % srows;
+  for (uint32_t p = res_ptr[i], e = res_ptr[i + 1]; p < e; ++p) {
+    keys[out0 + p] = (b << RG_KEY_BLK_SHIFT) | ((uint64_t)res_col[p] << RG_KEY_ACC_BITS) | (uint64_t)a;
+    src[out0 + p] = p;
+  }
 }
 __global__ void rg_fill_u64_kernel(uint64_t* __restrict__ p, uint64_t n, uint64_t v) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -282,33 +397,32 @@ __device__ __forceinline__ uint32_t rg_find_block(const uint64_t* __restrict__ p
 
 // One thread per padded entry position (in sorted order inside its chunk): write the entry word, accumulator and
 // value at the position the kernel's lanes read them from, and remember where the value came from.
+// (first_wide = 8 * ng: the cold part and the short-row blocks use the wide chunk format; first_short = 9 * ng.)
 template <class T>
 __global__ void rg_fill_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ src_sorted,
                                const uint64_t* __restrict__ start, const uint64_t* __restrict__ pe,
-                               const uint64_t* __restrict__ blk_off, const uint32_t* __restrict__ grp_row,
-                               const uint32_t* __restrict__ grp_sub, uint32_t nb,
-                               uint32_t ng, uint32_t abits, const T* __restrict__ vals, unsigned char* __restrict__ stream,
-                               uint32_t* __restrict__ vsrc, uint64_t padded) {
+                               const RgBlk* __restrict__ blk, uint32_t nb, uint32_t first_wide, uint32_t first_short,
+                               uint32_t abits, const T* __restrict__ vals, const T* __restrict__ short_vals,
+                               unsigned char* __restrict__ stream, uint32_t* __restrict__ vsrc, uint64_t padded) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= padded) return;
   const uint32_t b = rg_find_block(pe, nb, q);
-  const uint32_t part = b / ng, g = b - part * ng;
-  const bool wide = part == (uint32_t)SPMV_NSLAB;
+  const bool is_short = b >= first_short, wide = b >= first_wide;
+  const RgBlk bd = blk[b];
   const uint64_t jb = q - pe[b];
   const uint64_t chunk = jb >> 8;
   const uint32_t w = (uint32_t)(jb & 255u), lane = w & 63u, k = w >> 6;
   const uint64_t cnt = start[b + 1] - start[b];
-  // padding: the group's spare accumulator, behind its heads and extra accumulators
-  uint32_t idx = 0, a = (grp_row[g + 1] - grp_row[g]) + (grp_sub[g + 1] - grp_sub[g]), p = RG_NONE;
+  uint32_t idx = 0, a = bd.nheads + bd.nsubs, p = RG_NONE;  // padding: the block's spare accumulator
   T v = T(0);
   if (jb < cnt) {
     const uint64_t key = keys[start[b] + jb];
     idx = (uint32_t)(key >> RG_KEY_ACC_BITS);
     a = (uint32_t)(key & ((1u << RG_KEY_ACC_BITS) - 1u));
     p = src_sorted[start[b] + jb];
-    v = vals[p];
+    v = is_short ? short_vals[p] : vals[p];
   }
-  unsigned char* c = stream + blk_off[b] + chunk * (wide ? rg_chunk_bytes<T>(true) : rg_chunk_bytes<T>(false));
+  unsigned char* c = stream + bd.off + chunk * (wide ? rg_chunk_bytes<T>(true) : rg_chunk_bytes<T>(false));
   const uint32_t wpos = 4u * lane + k;
   if (wide) {
     reinterpret_cast<uint32_t*>(c)[wpos] = idx;
@@ -323,18 +437,19 @@ __global__ void rg_fill_kernel(const uint64_t* __restrict__ keys, const uint32_t
 
 // spam_csr_values_changed: one thread per padded value position
 template <class T>
-__global__ void rg_refresh_kernel(const uint64_t* __restrict__ pe, const uint64_t* __restrict__ blk_off, uint32_t nb, uint32_t ng,
-                                  const uint32_t* __restrict__ vsrc, const T* __restrict__ vals,
+__global__ void rg_refresh_kernel(const uint64_t* __restrict__ pe, const RgBlk* __restrict__ blk, uint32_t nb,
+                                  uint32_t first_wide, uint32_t first_short, const uint32_t* __restrict__ vsrc,
+                                  const T* __restrict__ vals, const T* __restrict__ short_vals,
                                   unsigned char* __restrict__ stream, uint64_t padded) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= padded) return;
   const uint32_t p = vsrc[q];
   if (p == RG_NONE) return;
   const uint32_t b = rg_find_block(pe, nb, q);
-  const bool wide = b / ng == (uint32_t)SPMV_NSLAB;
+  const bool is_short = b >= first_short, wide = b >= first_wide;
   const uint64_t jb = q - pe[b];
-  unsigned char* c = stream + blk_off[b] + (jb >> 8) * (wide ? rg_chunk_bytes<T>(true) : rg_chunk_bytes<T>(false));
-  reinterpret_cast<T*>(c + (wide ? 1536 : 1024))[jb & 255u] = vals[p];
+  unsigned char* c = stream + blk[b].off + (jb >> 8) * (wide ? rg_chunk_bytes<T>(true) : rg_chunk_bytes<T>(false));
+  reinterpret_cast<T*>(c + (wide ? 1536 : 1024))[jb & 255u] = is_short ? short_vals[p] : vals[p];
 }
 
 static int bits_for(uint64_t v) {  // bits needed to represent values 0..v
@@ -376,11 +491,18 @@ static int rg_dispatch(const RgPlan* g, const RgArgs<T>* args, hipStream_t s, un
   return set_error(SPAM_E_INVALID, "no row-group SpMV kernel for %d threads x %d chunks", g->nt, g->k);
 }
 
+struct RgGroup {
+  uint32_t heads[SPMV_NPART];
+  uint32_t nsubs;
+  uint32_t first_rank;
+  std::vector<uint32_t> sub_rank, sub_cnt;  // ranks with extra accumulators, and how many
+};
+
 }  // namespace
 
 void rg_plan_free(RgPlan* g) {
   if (!g) return;
-  void* ptrs[] = {g->stream, g->blk_off, g->pe, g->grp_row, g->grp_sub, g->sub_head, g->rank_rows, g->vsrc};
+  void* ptrs[] = {g->stream, g->blk, g->pe, g->sub_head, g->rank_rows, g->mask_rank, g->tiles, g->grp_cp, g->cp, g->vsrc};
   for (void* p : ptrs)
     if (p) dev_free(p);
   delete g;
@@ -388,7 +510,7 @@ void rg_plan_free(RgPlan* g) {
 
 template <class T>
 int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const uint32_t* long_rows, uint32_t nl, uint32_t S,
-             const RgKnobs& kn, hipStream_t s, RgPlan** out) {
+             const spam_csr* res, uint32_t ns, const RgKnobs& kn, hipStream_t s, RgPlan** out) {
   *out = nullptr;
   if (nl == 0 || !a->row_ptr32) return SPAM_OK;
   // one word holds slot << abits | accumulator
@@ -396,19 +518,23 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   int abits = std::min(13, 32 - sbits);
   if (kn.acc_bits > 0) abits = std::min(abits, kn.acc_bits);
   if (abits < 9) return SPAM_OK;  // tables too wide for the packed word: the caller keeps the tile form
-  const uint32_t rmax = (1u << abits) - 1u;  // usable accumulators of a group (+ 1 spare for the padding entries)
+  const uint32_t rmax = (1u << abits) - 1u;  // usable accumulators of a block (+ 1 spare for the padding entries)
   const uint64_t eblk = (uint64_t)std::max(1024, kn.eblk);
   const uint64_t ecap = eblk * SPMV_NPART;  // entries of a group over its nine blocks
+  const uint64_t max_sub = std::min<uint64_t>(RG_MAX_SUB, rmax / 2);
 
-  // -- long rows by length ------------------------------------------------------------------------------------------
-  DevBuf len, key_in, key_out, idx_in, idx_out, tmp;
+  // -- sliced rows: length, part mask; ranks by length ----------------------------------------------------------------
+  DevBuf len, key_in, key_out, idx_in, idx_out, mask, tmp;
   SPAM_TRY(len.alloc((uint64_t)nl * 4));
   SPAM_TRY(key_in.alloc((uint64_t)nl * 4));
   SPAM_TRY(key_out.alloc((uint64_t)nl * 4));
   SPAM_TRY(idx_in.alloc((uint64_t)nl * 4));
   SPAM_TRY(idx_out.alloc((uint64_t)nl * 4));
+  SPAM_TRY(mask.alloc((uint64_t)nl * 2));
   const unsigned gl = (nl + 255) / 256;
-  rg_len_kernel<<<gl, 256, 0, s>>>(a->row_ptr32, long_rows, nl, len.as<uint32_t>(), key_in.as<uint32_t>(), idx_in.as<uint32_t>());
+  const unsigned gw = (unsigned)(((uint64_t)nl * 64 + 255) / 256);
+  rg_row_kernel<<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, slab, long_rows, nl, (uint32_t)std::max(1, kn.order_min),
+                                   len.as<uint32_t>(), key_in.as<uint32_t>(), idx_in.as<uint32_t>(), mask.as<uint16_t>());
   SPAM_CHECK_LAUNCH();
   size_t tb = 0;
   SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key_in.as<uint32_t>(), key_out.as<uint32_t>(), idx_in.as<uint32_t>(),
@@ -416,9 +542,18 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_TRY(tmp.alloc(tb));
   SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key_in.as<uint32_t>(), key_out.as<uint32_t>(), idx_in.as<uint32_t>(),
                                                   idx_out.as<uint32_t>(), (int64_t)nl, 0, 32, s));
-  std::vector<uint32_t> h_key(nl), h_idx(nl);
-  SPAM_HIP_TRY(hipMemcpyAsync(h_key.data(), key_out.p, (uint64_t)nl * 4, hipMemcpyDeviceToHost, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(h_idx.data(), idx_out.p, (uint64_t)nl * 4, hipMemcpyDeviceToHost, s));
+  DevBuf rank_rows, rank_of, mask_rank;
+  SPAM_TRY(rank_rows.alloc((uint64_t)nl * 4));
+  SPAM_TRY(rank_of.alloc((uint64_t)nl * 4));
+  SPAM_TRY(mask_rank.alloc((uint64_t)nl * 2 + 2));
+  rg_rank_kernel<<<gl, 256, 0, s>>>(long_rows, idx_out.as<uint32_t>(), mask.as<uint16_t>(), len.as<uint32_t>(), nl,
+                                    rank_rows.as<uint32_t>(), rank_of.as<uint32_t>(), mask_rank.as<uint16_t>(),
+                                    key_in.as<uint32_t>() /* reused: lengths in rank order */);
+  SPAM_CHECK_LAUNCH();
+  std::vector<uint32_t> h_len(nl);
+  std::vector<uint16_t> h_mask(nl);
+  SPAM_HIP_TRY(hipMemcpyAsync(h_len.data(), key_in.p, (uint64_t)nl * 4, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(h_mask.data(), mask_rank.p, (uint64_t)nl * 2, hipMemcpyDeviceToHost, s));
   DevBuf lofs, stmp;
   SPAM_TRY(lofs.alloc(((uint64_t)nl + 1) * 8));
   SPAM_TRY(stmp.alloc(scan_tmp_bytes(nl)));
@@ -428,48 +563,95 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (n_ent == 0 || n_ent >= 0xFFFFFFFFull) return SPAM_OK;
 
-  // -- row groups (host): consecutive ranks, at most rmax accumulators and ecap entries ---------------------------------
-  std::vector<uint32_t> h_grp(nl), h_racc(nl), h_rsub(nl, 0u), h_grp_row(1, 0u), h_grp_sub(1, 0u), h_sub_head;
+  // -- row groups and tiles (host): consecutive ranks; per part at most rmax accumulators, ecap entries in all ----------
+  std::vector<uint32_t> h_grp(nl), h_rsub(nl), h_sub_head;
+  std::vector<RgTile> h_tiles;
+  std::vector<RgGroup> groups;
   {
-    uint32_t g = 0, accs = 0, nrows = 0, nsubs = 0, first = 0;
+    RgGroup cur{};
     uint64_t ents = 0;
-    std::vector<uint32_t> pending;  // (rank, extra accumulators) of the current group's rows that have some
-    auto close = [&](uint32_t end_rank) {
-      // the extra accumulators follow the group's heads: only now is the number of heads known
-      uint32_t sb = nrows;
-      for (size_t t = 0; t < pending.size(); t += 2) {
-        const uint32_t k = pending[t], extra = pending[t + 1];
-        h_rsub[h_idx[k]] = sb;
-        for (uint32_t j = 0; j < extra; ++j) h_sub_head.push_back(k - first);
-        sb += extra;
-      }
-      pending.clear();
-      h_grp_row.push_back(end_rank);
-      h_grp_sub.push_back((uint32_t)h_sub_head.size());
+    uint32_t in_tile = 0;
+    auto open_tile = [&](uint32_t k) {
+      RgTile t{};
+      t.row0 = k, t.grp = (uint32_t)groups.size(), t.n = 0;
+      for (int p = 0; p < SPMV_NPART; ++p) t.base[p] = (uint16_t)cur.heads[p];
+      h_tiles.push_back(t);
+      in_tile = 0;
     };
+    open_tile(0);
     for (uint32_t k = 0; k < nl; ++k) {
-      const uint64_t L = (uint64_t)(~h_key[k]);
+      const uint64_t L = h_len[k];
       // a row holding the fraction f of a block's entries draws 64 f lanes of every wave instruction: 8 x as many
       // accumulators keep two lanes off one LDS address most of the time
       uint64_t nsub = (L * RG_MAX_SUB + ecap - 1) / ecap;
-      nsub = std::min<uint64_t>(std::max<uint64_t>(nsub, 1), std::min<uint64_t>(RG_MAX_SUB, std::max<uint64_t>(L, 1)));
-      if (accs + nsub > rmax || (ents > 0 && ents + L > ecap)) {
-        close(k);
-        ++g, accs = 0, ents = 0, nrows = 0, nsubs = 0, first = k;
+      nsub = std::min<uint64_t>(std::max<uint64_t>(nsub, 1), std::min<uint64_t>(max_sub, std::max<uint64_t>(L, 1)));
+      if (nsub > 1) h_mask[k] = (uint16_t)RG_FULL_MASK;  // its extra accumulators exist in every part: so do its heads
+      const uint32_t m = h_mask[k];
+      uint32_t worst = 0;
+      for (int p = 0; p < SPMV_NPART; ++p) worst = std::max(worst, cur.heads[p] + ((m >> p) & 1u));
+      if (worst + cur.nsubs + (nsub - 1) > rmax || (ents > 0 && ents + L > ecap)) {
+        groups.push_back(cur);
+        cur = RgGroup{};
+        cur.first_rank = k;
+        ents = 0;
+        open_tile(k);
+      } else if (in_tile == 64) {
+        open_tile(k);
       }
-      const uint32_t i = h_idx[k];
-      h_grp[i] = g;
-      h_racc[i] = nrows | ((uint32_t)nsub << 16);
-      if (nsub > 1) pending.push_back(k), pending.push_back((uint32_t)nsub - 1);
-      accs += (uint32_t)nsub, ents += L, ++nrows, nsubs += (uint32_t)nsub - 1;
+      h_grp[k] = (uint32_t)groups.size();
+      h_rsub[k] = cur.nsubs | ((uint32_t)nsub << 16);
+      if (nsub > 1) cur.sub_rank.push_back(k), cur.sub_cnt.push_back((uint32_t)nsub - 1), cur.nsubs += (uint32_t)nsub - 1;
+      for (int p = 0; p < SPMV_NPART; ++p) cur.heads[p] += (m >> p) & 1u;
+      ents += L;
+      h_tiles.back().n = (uint16_t)(++in_tile);
     }
-    close(nl);
+    groups.push_back(cur);
   }
-  const uint32_t ng = (uint32_t)h_grp_row.size() - 1;
-  const uint64_t nb64 = (uint64_t)ng * SPMV_NPART;
+  const uint32_t ng = (uint32_t)groups.size();
+  const uint32_t ntiles = (uint32_t)h_tiles.size();
+  // short rows (the residual CSR, compacted by the caller): groups of rmax consecutive rows behind the nine parts
+  const bool fold = kn.fold_short && res && ns > 0 && res->nnz > 0;
+  const uint32_t srows = rmax;
+  const uint32_t ngs = fold ? (ns + srows - 1) / srows : 0;
+  const uint64_t n_short = fold ? res->nnz : 0;
+  if (n_ent + n_short >= 0xFFFFFFFFull) return SPAM_OK;
+  const uint64_t nb64 = (uint64_t)ng * SPMV_NPART + ngs;
   const int bbits = bits_for(nb64 - 1);
   if (RG_KEY_BLK_SHIFT + bbits > 64) return SPAM_OK;
-  const uint32_t nb = (uint32_t)nb64;
+  const uint32_t nb = (uint32_t)nb64, first_wide = ng * SPMV_NSLAB, first_short = ng * SPMV_NPART;
+
+  // block descriptors (stream offsets follow once the entries are counted); pairs in (group, part) order
+  std::vector<RgBlk> h_blk((size_t)nb + 1, RgBlk{});
+  std::vector<uint64_t> h_grp_cp((size_t)ng * SPMV_NPART);
+  uint64_t npairs = 0;
+  for (uint32_t g = 0; g < ng; ++g)
+    for (int p = 0; p < SPMV_NPART; ++p) {
+      RgBlk& b = h_blk[(size_t)p * ng + g];
+      b.nheads = groups[g].heads[p], b.nsubs = groups[g].nsubs, b.cp0 = npairs;
+      h_grp_cp[(size_t)g * SPMV_NPART + p] = npairs;
+      npairs += b.nheads;
+    }
+  for (uint32_t gs = 0; gs < ngs; ++gs) {
+    RgBlk& b = h_blk[(size_t)first_short + gs];
+    b.cp0 = (uint64_t)gs * srows, b.nheads = std::min(srows, ns - gs * srows);
+  }
+  // extra accumulators: per block, the head of each inside that block (a rank's head index differs from part to part)
+  for (uint32_t gi = 0; gi < ng; ++gi) {
+    const RgGroup& G = groups[gi];
+    if (G.nsubs == 0) continue;
+    for (int p = 0; p < SPMV_NPART; ++p) {
+      h_blk[(size_t)p * ng + gi].sub0 = (uint32_t)h_sub_head.size();
+      size_t si = 0;
+      uint32_t c = 0;  // pairs of part p among the group's ranks before k (the rule of rg_hidx_kernel)
+      for (uint32_t k = G.first_rank; si < G.sub_rank.size(); ++k) {
+        if (k == G.sub_rank[si]) {
+          for (uint32_t j = 0; j < G.sub_cnt[si]; ++j) h_sub_head.push_back(c);
+          ++si;
+        }
+        c += (h_mask[k] >> p) & 1u;
+      }
+    }
+  }
 
   RgPlan* g = new (std::nothrow) RgPlan();
   if (!g) return set_error(SPAM_E_OOM, "host allocation failed");
@@ -477,91 +659,105 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
     RgPlan* g;
     ~Guard() { if (g) rg_plan_free(g); }
   } guard{g};
-  g->ng = ng, g->abits = (uint32_t)abits, g->entries = n_ent, g->naccs = (uint64_t)nl + h_sub_head.size();
+  g->ng = ng, g->abits = (uint32_t)abits, g->entries = n_ent + n_short, g->npairs = npairs, g->ntiles = ntiles, g->nl = nl;
+  g->ngs = ngs, g->ns = fold ? ns : 0;
   g->nt = kn.nt, g->k = kn.k;
   g->lds_bytes = (rmax + 1u) * 8u;
+  g->naccs = npairs + h_sub_head.size();
 
-  DevBuf row_grp, row_acc, row_sub, grp_row, grp_sub, sub_head, rank_rows;
-  SPAM_TRY(row_grp.alloc((uint64_t)nl * 4));
-  SPAM_TRY(row_acc.alloc((uint64_t)nl * 4));
-  SPAM_TRY(row_sub.alloc((uint64_t)nl * 4));
-  SPAM_TRY(grp_row.alloc(((uint64_t)ng + 1) * 4));
-  SPAM_TRY(grp_sub.alloc(((uint64_t)ng + 1) * 4));
-  SPAM_TRY(sub_head.alloc(h_sub_head.size() * 4 + 4));
-  SPAM_TRY(rank_rows.alloc((uint64_t)nl * 4));
-  SPAM_HIP_TRY(hipMemcpyAsync(row_grp.p, h_grp.data(), (uint64_t)nl * 4, hipMemcpyHostToDevice, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(row_acc.p, h_racc.data(), (uint64_t)nl * 4, hipMemcpyHostToDevice, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(row_sub.p, h_rsub.data(), (uint64_t)nl * 4, hipMemcpyHostToDevice, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(grp_row.p, h_grp_row.data(), ((uint64_t)ng + 1) * 4, hipMemcpyHostToDevice, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(grp_sub.p, h_grp_sub.data(), ((uint64_t)ng + 1) * 4, hipMemcpyHostToDevice, s));
-  if (!h_sub_head.empty())
-    SPAM_HIP_TRY(hipMemcpyAsync(sub_head.p, h_sub_head.data(), h_sub_head.size() * 4, hipMemcpyHostToDevice, s));
-  rg_rank_rows_kernel<<<gl, 256, 0, s>>>(long_rows, idx_out.as<uint32_t>(), nl, rank_rows.as<uint32_t>());
+  DevBuf rk_grp, rk_sub, tiles, hidx, blk;
+  SPAM_TRY(rk_grp.alloc((uint64_t)nl * 4));
+  SPAM_TRY(rk_sub.alloc((uint64_t)nl * 4));
+  SPAM_TRY(tiles.alloc((uint64_t)ntiles * sizeof(RgTile)));
+  SPAM_TRY(hidx.alloc((uint64_t)nl * SPMV_NPART * 2));
+  SPAM_TRY(blk.alloc(((uint64_t)nb + 1) * sizeof(RgBlk)));
+  SPAM_HIP_TRY(hipMemcpyAsync(rk_grp.p, h_grp.data(), (uint64_t)nl * 4, hipMemcpyHostToDevice, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(rk_sub.p, h_rsub.data(), (uint64_t)nl * 4, hipMemcpyHostToDevice, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(tiles.p, h_tiles.data(), (uint64_t)ntiles * sizeof(RgTile), hipMemcpyHostToDevice, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(mask_rank.p, h_mask.data(), (uint64_t)nl * 2, hipMemcpyHostToDevice, s));  // (forced masks)
+  SPAM_HIP_TRY(hipMemcpyAsync(blk.p, h_blk.data(), ((uint64_t)nb + 1) * sizeof(RgBlk), hipMemcpyHostToDevice, s));
+  rg_hidx_kernel<<<(ntiles + 3) / 4, 256, 0, s>>>(tiles.as<RgTile>(), ntiles, mask_rank.as<uint16_t>(), hidx.as<uint16_t>());
   SPAM_CHECK_LAUNCH();
 
   // -- entries: key, sort by (block, slot) -------------------------------------------------------------------------------
   DevBuf keys_in, keys_out, src_in, src_out;
-  SPAM_TRY(keys_in.alloc(n_ent * 8));
-  SPAM_TRY(keys_out.alloc(n_ent * 8));
-  SPAM_TRY(src_in.alloc(n_ent * 4));
-  SPAM_TRY(src_out.alloc(n_ent * 4));
-  const unsigned gw = (unsigned)(((uint64_t)nl * 64 + 255) / 256);
-  rg_keys_kernel<<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, code, slab, long_rows, nl, lofs.as<uint64_t>(), row_grp.as<uint32_t>(),
-                                    row_acc.as<uint32_t>(), row_sub.as<uint32_t>(), ng, keys_in.as<uint64_t>(), src_in.as<uint32_t>());
+  const uint64_t n_all = n_ent + n_short;
+  SPAM_TRY(keys_in.alloc(n_all * 8));
+  SPAM_TRY(keys_out.alloc(n_all * 8));
+  SPAM_TRY(src_in.alloc(n_all * 4));
+  SPAM_TRY(src_out.alloc(n_all * 4));
+  rg_keys_kernel<<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, code, slab, long_rows, nl, lofs.as<uint64_t>(), rank_of.as<uint32_t>(),
+                                    rk_grp.as<uint32_t>(), rk_sub.as<uint32_t>(), hidx.as<uint16_t>(), blk.as<RgBlk>(), ng,
+                                    keys_in.as<uint64_t>(), src_in.as<uint32_t>());
   SPAM_CHECK_LAUNCH();
+  if (fold) {
+    rg_short_keys_kernel<<<(ns + 255) / 256, 256, 0, s>>>(res->row_ptr32, res->col_idx, ns, srows, (uint64_t)first_short, n_ent,
+                                                         keys_in.as<uint64_t>(), src_in.as<uint32_t>());
+    SPAM_CHECK_LAUNCH();
+  }
   const int end_bit = RG_KEY_BLK_SHIFT + bbits;
   tb = 0;
   SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), src_in.as<uint32_t>(),
-                                                  src_out.as<uint32_t>(), (int64_t)n_ent, RG_KEY_ACC_BITS, end_bit, s));
+                                                  src_out.as<uint32_t>(), (int64_t)n_all, RG_KEY_ACC_BITS, end_bit, s));
   SPAM_TRY(tmp.alloc(tb));
   SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), src_in.as<uint32_t>(),
-                                                  src_out.as<uint32_t>(), (int64_t)n_ent, RG_KEY_ACC_BITS, end_bit, s));
+                                                  src_out.as<uint32_t>(), (int64_t)n_all, RG_KEY_ACC_BITS, end_bit, s));
   SPAM_HIP_TRY(hipStreamSynchronize(s));  // the host vectors above are read by the copies
-  keys_in.reset(), src_in.reset(), tmp.reset();
+  keys_in.reset(), src_in.reset(), tmp.reset(), hidx.reset();
 
   // -- block bounds, chunk offsets ---------------------------------------------------------------------------------------
   DevBuf start;
   SPAM_TRY(start.alloc(((uint64_t)nb + 1) * 8));
   rg_fill_u64_kernel<<<(nb + 1 + 255) / 256, 256, 0, s>>>(start.as<uint64_t>(), (uint64_t)nb + 1, ~0ull);
   SPAM_CHECK_LAUNCH();
-  rg_bounds_kernel<<<(unsigned)((n_ent + 255) / 256), 256, 0, s>>>(keys_out.as<uint64_t>(), n_ent, start.as<uint64_t>());
+  rg_bounds_kernel<<<(unsigned)((n_all + 255) / 256), 256, 0, s>>>(keys_out.as<uint64_t>(), n_all, start.as<uint64_t>());
   SPAM_CHECK_LAUNCH();
-  std::vector<uint64_t> h_start((size_t)nb + 1), h_off((size_t)nb + 1), h_pe((size_t)nb + 1);
+  std::vector<uint64_t> h_start((size_t)nb + 1), h_pe((size_t)nb + 1);
   SPAM_HIP_TRY(hipMemcpyAsync(h_start.data(), start.p, ((uint64_t)nb + 1) * 8, hipMemcpyDeviceToHost, s));
   SPAM_HIP_TRY(hipStreamSynchronize(s));
-  h_start[nb] = n_ent;
+  h_start[nb] = n_all;
   for (uint32_t b = nb; b-- > 0;)
     if (h_start[b] == ~0ull) h_start[b] = h_start[b + 1];
-  h_off[0] = 0, h_pe[0] = 0;
-  uint64_t nonempty = 0;
+  h_pe[0] = 0;
+  uint64_t off = 0, nonempty = 0;
   for (uint32_t b = 0; b < nb; ++b) {
     const uint64_t cnt = h_start[b + 1] - h_start[b], nch = (cnt + 255) / 256;
-    const bool wide = b / ng == (uint32_t)SPMV_NSLAB;
-    h_off[b + 1] = h_off[b] + nch * rg_chunk_bytes<T>(wide);
+    h_blk[b].off = off, h_blk[b].nchunks = (uint32_t)nch;
+    off += nch * rg_chunk_bytes<T>(b >= first_wide);
     h_pe[b + 1] = h_pe[b] + nch * 256;
     nonempty += cnt != 0;
   }
-  g->stream_bytes = h_off[nb], g->padded = h_pe[nb], g->nonempty_blocks = nonempty;
-  DevBuf blk_off, pe, stream, vsrc;
-  SPAM_TRY(blk_off.alloc(((uint64_t)nb + 1) * 8));
+  h_blk[nb].off = off;
+  g->stream_bytes = off, g->padded = h_pe[nb], g->nonempty_blocks = nonempty;
+  DevBuf pe, stream, vsrc, sub_head, grp_cp, cp;
   SPAM_TRY(pe.alloc(((uint64_t)nb + 1) * 8));
   SPAM_TRY(stream.alloc(g->stream_bytes + 16));
   SPAM_TRY(vsrc.alloc(g->padded * 4 + 16));
+  SPAM_TRY(sub_head.alloc(h_sub_head.size() * 4 + 4));
+  SPAM_TRY(grp_cp.alloc((uint64_t)ng * SPMV_NPART * 8));
+  SPAM_TRY(cp.alloc((npairs + 2) * sizeof(T)));
+  SPAM_HIP_TRY(hipMemsetAsync(cp.p, 0, (npairs + 2) * sizeof(T), s));  // pairs without entries (forced masks) stay zero
   SPAM_HIP_TRY(hipMemcpyAsync(start.p, h_start.data(), ((uint64_t)nb + 1) * 8, hipMemcpyHostToDevice, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(blk_off.p, h_off.data(), ((uint64_t)nb + 1) * 8, hipMemcpyHostToDevice, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(blk.p, h_blk.data(), ((uint64_t)nb + 1) * sizeof(RgBlk), hipMemcpyHostToDevice, s));
   SPAM_HIP_TRY(hipMemcpyAsync(pe.p, h_pe.data(), ((uint64_t)nb + 1) * 8, hipMemcpyHostToDevice, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(grp_cp.p, h_grp_cp.data(), (uint64_t)ng * SPMV_NPART * 8, hipMemcpyHostToDevice, s));
+  if (!h_sub_head.empty())
+    SPAM_HIP_TRY(hipMemcpyAsync(sub_head.p, h_sub_head.data(), h_sub_head.size() * 4, hipMemcpyHostToDevice, s));
   rg_fill_kernel<T><<<(unsigned)((g->padded + 255) / 256), 256, 0, s>>>(
-      keys_out.as<uint64_t>(), src_out.as<uint32_t>(), start.as<uint64_t>(), pe.as<uint64_t>(), blk_off.as<uint64_t>(),
-      grp_row.as<uint32_t>(), grp_sub.as<uint32_t>(), nb, ng, (uint32_t)abits, (const T*)a->vals, stream.as<unsigned char>(), vsrc.as<uint32_t>(), g->padded);
+      keys_out.as<uint64_t>(), src_out.as<uint32_t>(), start.as<uint64_t>(), pe.as<uint64_t>(), blk.as<RgBlk>(), nb, first_wide,
+      first_short, (uint32_t)abits, (const T*)a->vals, fold ? (const T*)res->vals : nullptr, stream.as<unsigned char>(),
+      vsrc.as<uint32_t>(), g->padded);
   SPAM_CHECK_LAUNCH();
   SPAM_HIP_TRY(hipStreamSynchronize(s));  // host vectors and temporaries go out of scope
   g->stream = stream.as<unsigned char>(), stream.release();
-  g->blk_off = blk_off.as<uint64_t>(), blk_off.release();
+  g->blk = blk.release();
   g->pe = pe.as<uint64_t>(), pe.release();
-  g->grp_row = grp_row.as<uint32_t>(), grp_row.release();
-  g->grp_sub = grp_sub.as<uint32_t>(), grp_sub.release();
   g->sub_head = sub_head.as<uint32_t>(), sub_head.release();
   g->rank_rows = rank_rows.as<uint32_t>(), rank_rows.release();
+  g->mask_rank = mask_rank.as<uint16_t>(), mask_rank.release();
+  g->tiles = tiles.release();
+  g->grp_cp = grp_cp.as<uint64_t>(), grp_cp.release();
+  g->cp = cp.release();
   g->vsrc = vsrc.as<uint32_t>(), vsrc.release();
   RgArgs<T> none{};
   SPAM_TRY(rg_dispatch<T>(g, &none, s, &g->grid));
@@ -571,29 +767,36 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
 }
 
 template <class T>
-int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, T* partial, uint32_t nl, uint32_t* queue, hipStream_t s) {
+int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, uint32_t* queue, T* y, const uint32_t* short_rows,
+           hipStream_t s) {
   RgArgs<T> P;
-  P.blk_off = g->blk_off, P.grp_row = g->grp_row, P.grp_sub = g->grp_sub, P.sub_head = g->sub_head, P.stream = g->stream;
+  P.blk = (const RgBlk*)g->blk, P.sub_head = g->sub_head, P.stream = g->stream;
   for (int p = 0; p < SPMV_NSLAB; ++p) P.base[p] = xh + (uint64_t)p * S;
   P.base[SPMV_NSLAB] = x;
-  P.partial = partial, P.queue = queue, P.ng = g->ng, P.nl = nl, P.abits = g->abits;
-  return rg_dispatch<T>(g, &P, s, nullptr);
+  P.cp = (T*)g->cp, P.queue = queue, P.ng = g->ng, P.abits = g->abits;
+  P.y = y, P.short_rows = short_rows, P.ngs = g->ngs;
+  SPAM_TRY(rg_dispatch<T>(g, &P, s, nullptr));
+  spmv_rg_reduce_kernel<T><<<(g->ntiles + 3) / 4, 256, 0, s>>>((const RgTile*)g->tiles, g->ntiles, g->mask_rank, g->rank_rows,
+                                                              g->grp_cp, (const T*)g->cp, y);
+  SPAM_CHECK_LAUNCH();
+  return SPAM_OK;
 }
 
 template <class T>
-int rg_refresh_values(const spam_csr* a, RgPlan* g, hipStream_t s) {
+int rg_refresh_values(const spam_csr* a, const spam_csr* res, RgPlan* g, hipStream_t s) {
   if (g->padded == 0) return SPAM_OK;
-  rg_refresh_kernel<T><<<(unsigned)((g->padded + 255) / 256), 256, 0, s>>>(g->pe, g->blk_off, g->ng * SPMV_NPART, g->ng, g->vsrc,
-                                                                          (const T*)a->vals, g->stream, g->padded);
+  rg_refresh_kernel<T><<<(unsigned)((g->padded + 255) / 256), 256, 0, s>>>(
+      g->pe, (const RgBlk*)g->blk, g->ng * SPMV_NPART + g->ngs, g->ng * SPMV_NSLAB, g->ng * SPMV_NPART, g->vsrc,
+      (const T*)a->vals, g->ngs ? (const T*)res->vals : nullptr, g->stream, g->padded);
   SPAM_CHECK_LAUNCH();
   return SPAM_OK;
 }
 
 #define SPAM_RG_INSTANTIATE(T)                                                                                              \
   template int rg_build<T>(const spam_csr*, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t,            \
-                           const RgKnobs&, hipStream_t, RgPlan**);                                                           \
-  template int rg_run<T>(const RgPlan*, const T*, uint32_t, const T*, T*, uint32_t, uint32_t*, hipStream_t);                 \
-  template int rg_refresh_values<T>(const spam_csr*, RgPlan*, hipStream_t);
+                           const spam_csr*, uint32_t, const RgKnobs&, hipStream_t, RgPlan**);                                \
+  template int rg_run<T>(const RgPlan*, const T*, uint32_t, const T*, uint32_t*, T*, const uint32_t*, hipStream_t);          \
+  template int rg_refresh_values<T>(const spam_csr*, const spam_csr*, RgPlan*, hipStream_t);
 SPAM_RG_INSTANTIATE(double)
 SPAM_RG_INSTANTIATE(float)
 SPAM_RG_INSTANTIATE(i64w)

@@ -29,7 +29,7 @@ def pmc(prefix):
             name = row["Kernel_Name"]
             if "spam::" not in name:
                 continue
-            short = name.split("spam::")[1].split("(")[0].split("<")[0]
+            short = name.split("spam::")[1].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
             agg[(short, row["Counter_Name"])][0] += float(row["Counter_Value"])
             agg[(short, row["Counter_Name"])][1] += 1
     return agg
@@ -54,7 +54,9 @@ except OSError:
 # ---- SpMV step ------------------------------------------------------------------------------------
 sp = pmc("spmv_pmc_")
 mode = bench.get("config", {}).get("spmv_plan", {}).get("mode", "?")
-step_kernels = (["sliced_build_tables_kernel", "xh_build_kernel", "spmv_short_rows_kernel", "spmv_sliced_pipe_kernel",
+step_kernels = (["sliced_build_tables_kernel", "xh_build_kernel", "spmv_short_rows_kernel", "spmv_rg_kernel", "spmv_rg_reduce_kernel"]
+                if mode == "xcd_sliced_row_groups" else
+                ["sliced_build_tables_kernel", "xh_build_kernel", "spmv_short_rows_kernel", "spmv_sliced_pipe_kernel",
                  "sliced_fixup_kernel", "sliced_reduce_kernel"] if mode == "xcd_sliced" else
                 ["xh_build_kernel", "spmv_tile_kernel", "spmv_fixup_kernel"])
 lines.append("\n== SpMV PMC, per-dispatch averages (bench.py --steps 5 --warmup 1 --spgemm-scale 0); plan: " + mode)
@@ -67,7 +69,7 @@ if fetch and write:
     traffic = (2 * sum(fetch.values()) + sum(write.values())) * 1024
     json.dump({"kernels": step_kernels, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
                "formula": "2*FETCH_SIZE + WRITE_SIZE summed over the kernels of one step (gfx950: FETCH_SIZE counts 128-byte reads as 64)",
-               "traffic_bytes_per_launch": traffic, "kernel_source_sha16": src_hash("spam_spmv.hip"),
+               "traffic_bytes_per_launch": traffic, "kernel_source_sha16": src_hash("spam_spmv.hip", "spam_spmv_rg.hip"),
                "workload": {"rows": bench.get("config", {}).get("rows"), "nnz": bench.get("config", {}).get("nnz"), "plan": mode},
                "algorithmic_bytes": bench.get("roofline", {}).get("algorithmic_bytes")},
               open(out + "/spmv_pmc_latest.json", "w"), indent=1)
