@@ -129,17 +129,24 @@ constexpr int SPMV_HEAD_STRIDE = 64;        // u32 words between two queue heads
 
 // ---- SpMV, row-group form of the sliced path's long rows (spam_spmv_rg.hip) ------------------------------------------
 struct RgKnobs {
-  int eblk = 150000;  // SPAM_SPMV_RG_EBLK   entries of a (part, row group) block aimed at
+  int eblk = 200000;  // SPAM_SPMV_RG_EBLK   entries of a (part, row group) block aimed at
   int nt = 512;       // SPAM_SPMV_RG_NT     threads per workgroup (256 / 512 / 1024)
   int k = 4;          // SPAM_SPMV_RG_K      chunks a wavefront keeps in flight
   int acc_bits = 0;   // SPAM_SPMV_RG_ABITS  cap on the accumulator bits of an entry word (0: as many as fit, at most 13)
   int fold_short = 1; // SPAM_SPMV_RG_SHORT  the short rows as blocks of the same kernel (0: spmv_short_rows_kernel)
+  int tpw = 1;        // SPAM_SPMV_RG_TPW    tiles a wavefront of the reduce kernel keeps in flight (1 / 2 / 4)
+  int prefetch = 0;   // SPAM_SPMV_RG_PREFETCH  draw a queue's next ticket while the current block streams
+  int zero_fill = 0;  // SPAM_SPMV_RG_ZERO   the reduce kernel also zeroes the empty rows instead of a zero-fill of y (measured 1 % slower)
+  int prof = 0;       // SPAM_SPMV_PROF = 3   per-block phase timers, printed by every SpMV (diagnostics)
   int order_min = 32; // SPAM_SPMV_RG_ORDER  rows with fewer entries are ranked in row order (coalesced y writes), longer ones by length
 };
 struct RgPlan {
   uint32_t ng = 0, abits = 0, lds_bytes = 0, nl = 0, ntiles = 0;
+  uint32_t ord0 = 0, rows = 0;      // ranks from ord0 on are rows in ascending order
+  bool zero_by_reduce = false;      // spmv_rg_reduce_kernel also zeroes the empty rows of y
+  uint64_t* nonempty = nullptr;     // u64[(rows + 63) / 64]: rows with entries (only with zero_by_reduce)
   uint32_t ngs = 0, ns = 0;         // short-row blocks (0: no short rows, or they keep their own kernel)
-  int nt = 512, k = 4;
+  int nt = 512, k = 4, prof = 0, tpw = 1, prefetch = 0;
   unsigned grid = 0;
   uint64_t stream_bytes = 0, entries = 0, padded = 0, naccs = 0, npairs = 0, nonempty_blocks = 0;
   unsigned char* stream = nullptr;  // the blocks' chunks, part-major

@@ -704,6 +704,10 @@ static SpmvKnobs read_knobs() {
   k.rgk.acc_bits = env_int("SPAM_SPMV_RG_ABITS", 0);
   k.rgk.fold_short = env_int("SPAM_SPMV_RG_SHORT", 1);
   k.rgk.order_min = env_int("SPAM_SPMV_RG_ORDER", k.rgk.order_min);
+  k.rgk.prof = k.prof;
+  k.rgk.zero_fill = env_int("SPAM_SPMV_RG_ZERO", k.rgk.zero_fill);
+  k.rgk.tpw = env_int("SPAM_SPMV_RG_TPW", k.rgk.tpw);
+  k.rgk.prefetch = env_int("SPAM_SPMV_RG_PREFETCH", k.rgk.prefetch);
   return k;
 }
 
@@ -1055,7 +1059,7 @@ __global__ __launch_bounds__(256) void spmv_short_rows_kernel(const uint32_t* __
 template <class T>
 __global__ void sliced_build_tables_kernel(const T* __restrict__ x, const uint32_t* __restrict__ dest, uint32_t cols,
                                            T* __restrict__ xh, uint32_t* __restrict__ heads, T* __restrict__ y,
-                                           uint32_t rows) {
+                                           uint32_t rows) {  // rows = 0: y is zero-filled elsewhere (row-group reduce)
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= NPART) heads[i * HEAD_STRIDE] = 0;
   if (i < rows) y[i] = T(0);
@@ -1559,7 +1563,8 @@ template <class T>
 static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, hipStream_t s) {
   const uint32_t cols = (uint32_t)a->cols;
   const uint32_t rows = (uint32_t)a->rows;
-  sliced_build_tables_kernel<T><<<(unsigned)(((uint64_t)std::max(cols, rows) + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
+  const uint32_t zrows = q->rg && q->rg->zero_by_reduce ? 0u : rows;
+  sliced_build_tables_kernel<T><<<(unsigned)(((uint64_t)std::max(cols, zrows) + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, zrows);
   SPAM_CHECK_LAUNCH();
   // (running the short rows beside the slab kernel on a second stream was measured 3 % slower than one after the other)
   if (!(q->rg && q->rg->ngs)) SPAM_TRY(residual_run<T>(a, q, x, y, s));

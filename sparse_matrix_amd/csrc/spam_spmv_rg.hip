@@ -90,7 +90,8 @@ struct RgTile {
   uint32_t grp;
   uint16_t n;                   // ranks in the tile
   uint16_t base[SPMV_NPART];    // pairs of the group's earlier tiles, per part
-  uint16_t pad[2];
+  uint16_t ordered;             // its ranks are rows in ascending order (the ranks below RgKnobs::order_min entries)
+  uint16_t pad;
 };
 static_assert(sizeof(RgTile) == 32, "RgTile layout");
 
@@ -107,6 +108,8 @@ struct RgArgs {
   T* y;
   const uint32_t* short_rows;
   uint32_t ngs;
+  uint32_t prefetch;          // draw the next ticket while the block streams
+  unsigned long long* times;  // diagnostics (SPAM_SPMV_PROF=3): per block 4 wall-clock stamps (100 MHz); else null
 };
 
 template <class T>
@@ -207,14 +210,19 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
   const uint32_t xcc = rg_xcc_id();
   const bool cold_first = ((blockIdx.x >> 3) & 3u) == 0u;
   int q = 0;
+  bool have = false;  // s_blk already holds this queue's next ticket (drawn while the previous block was streaming)
   for (;;) {
     uint32_t part;
     if (cold_first) part = q == 0 ? (uint32_t)SPMV_NSLAB : q == 1 ? RG_SHORT : q == 2 ? xcc : ((xcc + (uint32_t)(q - 2)) & 7u);
     else part = q == 0 ? xcc : q == 1 ? (uint32_t)SPMV_NSLAB : q == 2 ? RG_SHORT : ((xcc + (uint32_t)(q - 2)) & 7u);
-    if (threadIdx.x == 0) s_blk = atomicAdd(P.queue + (uint64_t)SPMV_HEAD_STRIDE * part, 1u);
-    __syncthreads();
+    uint32_t* qhead = P.queue + (uint64_t)SPMV_HEAD_STRIDE * part;
+    if (!have) {
+      __syncthreads();  // (everyone has read the previous ticket)
+      if (threadIdx.x == 0) s_blk = atomicAdd(qhead, 1u);
+      __syncthreads();
+    }
+    have = false;
     const uint32_t g = __builtin_amdgcn_readfirstlane(s_blk);
-    __syncthreads();
     const bool is_short = part == RG_SHORT;
     if (g >= (is_short ? P.ngs : P.ng)) {
       if (++q > SPMV_NSLAB + 1) break;
@@ -226,13 +234,24 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
     const uint64_t off = bd->off, cp0 = bd->cp0;
     const uint32_t nheads = bd->nheads, nsubs = bd->nsubs, sub0 = bd->sub0;
     const uint32_t na = nheads + nsubs;
+    // the next ticket of this queue: in flight while the block streams, published before the block's last barrier
+    uint32_t next_ticket = 0;
+    if (P.prefetch && threadIdx.x == 0) next_ticket = atomicAdd(qhead, 1u);
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (P.times) t0 = wall_clock64();
     for (uint32_t i = threadIdx.x; i <= na; i += NT) acc[i] = AccT(0);  // [na] takes the padding entries
     __syncthreads();
+    if (P.times) t1 = wall_clock64();
     if (part >= (uint32_t)SPMV_NSLAB)
       rg_stream<T, NT, K, true>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[SPMV_NSLAB], acc, P.abits);
     else
       rg_stream<T, NT, K, false>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc, P.abits);
     __syncthreads();
+    if (P.times) t2 = wall_clock64();
+    if (P.prefetch) {
+      if (threadIdx.x == 0) s_blk = next_ticket;
+      have = true;
+    }
     if (nsubs) {  // uniform
       for (uint32_t i = threadIdx.x; i < nsubs; i += NT) atomicAdd(&acc[P.sub_head[sub0 + i]], acc[nheads + i]);
       __syncthreads();
@@ -246,37 +265,100 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
       for (uint32_t i = threadIdx.x; i < nheads; i += NT) out[i] = (T)acc[i];
     }
     __syncthreads();
+    if (P.times && threadIdx.x == 0) {
+      unsigned long long* t = P.times + 4ull * ((uint64_t)part * P.ng + g);
+      t[0] = t0, t[1] = t1, t[2] = t2, t[3] = wall_clock64();
+    }
   }
 }
 
 // y[row of rank] = sum of the row's pairs, in part order.  One wavefront per tile of 64 ranks: a row's pair in part p is
 // the (tile base + number of earlier ranks of the tile with a pair in p)-th of block (p, group).
-template <class T>
+// The ranks from ord0 on are rows in ascending order (the rows below order_min entries): their tiles also zero the
+// EMPTY rows between two consecutive ones (and before the first / after the last), so that y needs no separate
+// zero-fill and the 8-byte stores of neighbouring lanes share their lines.  Rows that are not empty (longer rows, rows
+// of the unsliced short path) carry a bit in `nonempty` and are written by their own owner.
+// RG_TPW: tiles a wavefront of the reduce kernel keeps in flight
+template <class T, int RG_TPW>
 __global__ __launch_bounds__(256) void spmv_rg_reduce_kernel(const RgTile* __restrict__ tiles, uint32_t ntiles,
                                                              const uint16_t* __restrict__ mask_rank,
                                                              const uint32_t* __restrict__ rank_rows,
                                                              const uint64_t* __restrict__ grp_cp, const T* __restrict__ cp,
-                                                             T* __restrict__ y) {
-  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (t >= ntiles) return;
-  const RgTile tl = tiles[t];
-  const bool act = lane < tl.n;
-  const uint32_t k = tl.row0 + lane;
-  const uint32_t m = act ? mask_rank[k] : 0u;
+                                                             T* __restrict__ y, const uint64_t* __restrict__ nonempty,
+                                                             uint32_t nl, uint32_t ord0, uint32_t rows) {
+  const uint32_t t0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * RG_TPW, lane = threadIdx.x & 63u;
+  if (t0 >= ntiles) return;
   const uint64_t lt = (1ull << lane) - 1ull;
-  const uint64_t* gc = grp_cp + (uint64_t)tl.grp * SPMV_NPART;
-  T v[SPMV_NPART];
+  // every stage for all RG_TPW tiles before the next one: the tile -> mask -> pair chains of the tiles overlap
+  RgTile tl[RG_TPW];
 #pragma unroll
-  for (int p = 0; p < SPMV_NPART; ++p) {
-    const bool has = (m >> p) & 1u;
-    const uint64_t bal = __ballot(has);
-    const uint64_t at = gc[p] + tl.base[p] + (uint64_t)__popcll(bal & lt);
-    v[p] = has ? cp[at] : T(0);
+  for (int j = 0; j < RG_TPW; ++j) {
+    tl[j] = tiles[min(t0 + j, ntiles - 1)];
+    if (t0 + j >= ntiles) tl[j].n = 0;
   }
-  T s = v[0];
+  uint32_t m[RG_TPW], r[RG_TPW];
 #pragma unroll
-  for (int p = 1; p < SPMV_NPART; ++p) s += v[p];
-  if (act) y[rank_rows[k]] = s;
+  for (int j = 0; j < RG_TPW; ++j) {
+    const bool act = lane < tl[j].n;
+    const uint32_t k = tl[j].row0 + lane;
+    m[j] = act ? mask_rank[k] : 0u;
+    r[j] = act ? rank_rows[k] : 0u;
+  }
+  T v[RG_TPW][SPMV_NPART];
+#pragma unroll
+  for (int j = 0; j < RG_TPW; ++j) {
+    const uint64_t* gc = grp_cp + (uint64_t)tl[j].grp * SPMV_NPART;
+#pragma unroll
+    for (int p = 0; p < SPMV_NPART; ++p) {
+      const bool has = (m[j] >> p) & 1u;
+      const uint64_t bal = __ballot(has);
+      const uint64_t at = gc[p] + tl[j].base[p] + (uint64_t)__popcll(bal & lt);
+      v[j][p] = has ? cp[at] : T(0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RG_TPW; ++j) {
+    T s = v[j][0];
+#pragma unroll
+    for (int p = 1; p < SPMV_NPART; ++p) s += v[j][p];
+    if (lane < tl[j].n) y[r[j]] = s;
+  }
+  if (!nonempty) return;
+  // the row range of the wavefront's ORDERED tiles (they are consecutive ranks = ascending rows): from the first one's
+  // first row (from row 0 for the first ordered tile of all) up to the first row behind the last one (the end of y for
+  // the last tile); all lanes stride over it and zero the rows without entries
+  int jf = -1, jl = -1;
+#pragma unroll
+  for (int j = 0; j < RG_TPW; ++j)
+    if (tl[j].n && tl[j].ordered) {
+      if (jf < 0) jf = j;
+      jl = j;
+    }
+  if (jf < 0) return;  // (uniform)
+  uint32_t first_row = 0, kend = 0, row0f = 0;
+#pragma unroll
+  for (int j = 0; j < RG_TPW; ++j) {
+    if (j == jf) first_row = __shfl(r[j], 0, 64), row0f = tl[j].row0;
+    if (j == jl) kend = tl[j].row0 + tl[j].n;
+  }
+  const uint32_t lo = row0f == ord0 ? 0u : first_row;
+  const uint32_t hi = kend < nl ? rank_rows[kend] : rows;
+  for (uint32_t w0 = lo >> 6; (uint64_t)w0 * 64 < hi; w0 += 64) {  // 64 bitmap words = 4096 rows per pass
+    const uint32_t nw = min(64u, (hi + 63u) / 64u - w0);
+    const uint64_t myw = lane < nw ? nonempty[w0 + lane] : ~0ull;
+    for (uint32_t i = 0; i < nw; ++i) {
+      const uint64_t w = __shfl(myw, (int)i, 64);
+      const uint32_t q = (w0 + i) * 64u + lane;
+      if (q >= lo && q < hi && !((w >> lane) & 1ull)) y[q] = T(0);
+    }
+  }
+}
+
+__global__ void rg_nonempty_kernel(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint64_t* __restrict__ nonempty) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (whole wavefronts: rows rounded up to 64 by the grid)
+  const bool ne = r < rows && row_ptr[r + 1] > row_ptr[r];
+  const uint64_t bal = __ballot(ne);
+  if ((threadIdx.x & 63) == 0 && r < rows) nonempty[r >> 6] = bal;
 }
 
 // ---- plan construction ------------------------------------------------------------------------------------------
@@ -502,7 +584,7 @@ struct RgGroup {
 
 void rg_plan_free(RgPlan* g) {
   if (!g) return;
-  void* ptrs[] = {g->stream, g->blk, g->pe, g->sub_head, g->rank_rows, g->mask_rank, g->tiles, g->grp_cp, g->cp, g->vsrc};
+  void* ptrs[] = {g->stream, g->blk, g->pe, g->sub_head, g->rank_rows, g->mask_rank, g->tiles, g->grp_cp, g->cp, g->vsrc, g->nonempty};
   for (void* p : ptrs)
     if (p) dev_free(p);
   delete g;
@@ -563,6 +645,18 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (n_ent == 0 || n_ent >= 0xFFFFFFFFull) return SPAM_OK;
 
+  // ranks from ord0 on are the rows below order_min entries, in row order (rg_row_kernel's sort key)
+  uint32_t ord0 = nl;
+  {
+    const uint32_t om = (uint32_t)std::max(1, kn.order_min);
+    uint32_t lo = 0, hi = nl;  // lengths are non-increasing up to ord0; first rank with len < om
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (h_len[mid] < om) hi = mid;
+      else lo = mid + 1;
+    }
+    ord0 = lo;
+  }
   // -- row groups and tiles (host): consecutive ranks; per part at most rmax accumulators, ecap entries in all ----------
   std::vector<uint32_t> h_grp(nl), h_rsub(nl), h_sub_head;
   std::vector<RgTile> h_tiles;
@@ -573,13 +667,14 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
     uint32_t in_tile = 0;
     auto open_tile = [&](uint32_t k) {
       RgTile t{};
-      t.row0 = k, t.grp = (uint32_t)groups.size(), t.n = 0;
+      t.row0 = k, t.grp = (uint32_t)groups.size(), t.n = 0, t.ordered = k >= ord0;
       for (int p = 0; p < SPMV_NPART; ++p) t.base[p] = (uint16_t)cur.heads[p];
       h_tiles.push_back(t);
       in_tile = 0;
     };
     open_tile(0);
     for (uint32_t k = 0; k < nl; ++k) {
+      const bool ord_start = k == ord0 && k > 0;  // the row-ordered ranks start a tile of their own
       const uint64_t L = h_len[k];
       // a row holding the fraction f of a block's entries draws 64 f lanes of every wave instruction: 8 x as many
       // accumulators keep two lanes off one LDS address most of the time
@@ -595,7 +690,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
         cur.first_rank = k;
         ents = 0;
         open_tile(k);
-      } else if (in_tile == 64) {
+      } else if (in_tile == 64 || ord_start) {
         open_tile(k);
       }
       h_grp[k] = (uint32_t)groups.size();
@@ -661,10 +756,18 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   } guard{g};
   g->ng = ng, g->abits = (uint32_t)abits, g->entries = n_ent + n_short, g->npairs = npairs, g->ntiles = ntiles, g->nl = nl;
   g->ngs = ngs, g->ns = fold ? ns : 0;
-  g->nt = kn.nt, g->k = kn.k;
+  g->ord0 = ord0, g->rows = (uint32_t)a->rows, g->zero_by_reduce = kn.zero_fill && ord0 < nl;
+  g->nt = kn.nt, g->k = kn.k, g->prof = kn.prof, g->tpw = kn.tpw, g->prefetch = kn.prefetch;
   g->lds_bytes = (rmax + 1u) * 8u;
   g->naccs = npairs + h_sub_head.size();
 
+  DevBuf ne_bits;
+  if (g->zero_by_reduce) {
+    const uint64_t words = ((uint64_t)a->rows + 63) / 64;
+    SPAM_TRY(ne_bits.alloc(words * 8));
+    rg_nonempty_kernel<<<(unsigned)((words * 64 + 255) / 256), 256, 0, s>>>(a->row_ptr32, (uint32_t)a->rows, ne_bits.as<uint64_t>());
+    SPAM_CHECK_LAUNCH();
+  }
   DevBuf rk_grp, rk_sub, tiles, hidx, blk;
   SPAM_TRY(rk_grp.alloc((uint64_t)nl * 4));
   SPAM_TRY(rk_sub.alloc((uint64_t)nl * 4));
@@ -759,6 +862,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   g->grp_cp = grp_cp.as<uint64_t>(), grp_cp.release();
   g->cp = cp.release();
   g->vsrc = vsrc.as<uint32_t>(), vsrc.release();
+  g->nonempty = (uint64_t*)ne_bits.release();
   RgArgs<T> none{};
   SPAM_TRY(rg_dispatch<T>(g, &none, s, &g->grid));
   guard.g = nullptr;
@@ -775,9 +879,50 @@ int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, uint32_t* queue
   P.base[SPMV_NSLAB] = x;
   P.cp = (T*)g->cp, P.queue = queue, P.ng = g->ng, P.abits = g->abits;
   P.y = y, P.short_rows = short_rows, P.ngs = g->ngs;
+  P.times = nullptr, P.prefetch = (uint32_t)g->prefetch;
+  DevBuf tbuf;
+  const uint64_t nblk = (uint64_t)g->ng * SPMV_NPART + g->ngs;
+  if (g->prof == 3) {  // diagnostics: where the workgroups' time goes (one synchronous launch, stderr)
+    SPAM_TRY(tbuf.alloc(nblk * 32));
+    SPAM_HIP_TRY(hipMemsetAsync(tbuf.p, 0, nblk * 32, s));
+    P.times = tbuf.as<unsigned long long>();
+  }
   SPAM_TRY(rg_dispatch<T>(g, &P, s, nullptr));
-  spmv_rg_reduce_kernel<T><<<(g->ntiles + 3) / 4, 256, 0, s>>>((const RgTile*)g->tiles, g->ntiles, g->mask_rank, g->rank_rows,
-                                                              g->grp_cp, (const T*)g->cp, y);
+  if (P.times) {
+    std::vector<unsigned long long> h(nblk * 4);
+    SPAM_HIP_TRY(hipMemcpyAsync(h.data(), tbuf.p, nblk * 32, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+    unsigned long long lo = ~0ull, hi = 0;
+    double zero = 0, stream = 0, write = 0;
+    uint64_t ran = 0;
+    for (uint64_t b = 0; b < nblk; ++b) {
+      const unsigned long long* t = &h[4 * b];
+      if (!t[3]) continue;
+      lo = std::min(lo, t[0]), hi = std::max(hi, t[3]);
+      zero += (double)(t[1] - t[0]), stream += (double)(t[2] - t[1]), write += (double)(t[3] - t[2]);
+      ++ran;
+    }
+    const double span = (double)(hi - lo), cap = span * g->grid;
+    fprintf(stderr, "[spam] row-group SpMV kernel: %llu blocks on %u workgroups, span %.1f us; workgroup time: zero-fill %.1f %%, "
+            "stream %.1f %%, fold + store %.1f %%, between blocks (tickets, descriptors, idle at the end) %.1f %%\n",
+            (unsigned long long)ran, g->grid, span / 100.0, 100 * zero / cap, 100 * stream / cap, 100 * write / cap,
+            100 * (cap - zero - stream - write) / cap);
+    for (int p = 0; p <= SPMV_NPART; ++p) {
+      const uint64_t b0 = (uint64_t)p * g->ng, b1 = p < SPMV_NPART ? b0 + g->ng : nblk;
+      unsigned long long last = 0;
+      double st = 0;
+      for (uint64_t b = b0; b < b1; ++b) last = std::max(last, h[4 * b + 3]), st += h[4 * b + 3] ? (double)(h[4 * b + 2] - h[4 * b + 1]) : 0.0;
+      if (last) fprintf(stderr, "[spam]   part %d: last block ends at %.1f us, stream time summed %.0f us\n", p, (double)(last - lo) / 100.0, st / 100.0);
+    }
+  }
+#define SPAM_RG_REDUCE(TPW_)                                                                                          \
+  spmv_rg_reduce_kernel<T, TPW_><<<(g->ntiles + 4 * TPW_ - 1) / (4 * TPW_), 256, 0, s>>>(                              \
+      (const RgTile*)g->tiles, g->ntiles, g->mask_rank, g->rank_rows, g->grp_cp, (const T*)g->cp, y,                    \
+      g->zero_by_reduce ? g->nonempty : nullptr, g->nl, g->ord0, g->rows)
+  if (g->tpw >= 4) SPAM_RG_REDUCE(4);
+  else if (g->tpw == 2) SPAM_RG_REDUCE(2);
+  else SPAM_RG_REDUCE(1);
+#undef SPAM_RG_REDUCE
   SPAM_CHECK_LAUNCH();
   return SPAM_OK;
 }

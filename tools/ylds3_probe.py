@@ -209,6 +209,16 @@ def main():
             print("   part %d: entries %9d, blocks %d, last end %.1f us, served by own XCD %.2f, stream us mean %.1f max %.1f; zero %.1f write %.1f"
                   % (p, cnt[sl].sum(), ng, t[sl, 3].max(), own, (t[sl, 2] - t[sl, 1]).mean(), (t[sl, 2] - t[sl, 1]).max(),
                      (t[sl, 1] - t[sl, 0]).mean(), (t[sl, 3] - t[sl, 2]).mean()), flush=True)
+        if os.environ.get("YLDS_RATES"):
+            sl = slice(0, ng)  # part 0
+            st = (t[sl, 2] - t[sl, 1])
+            e = cnt[sl].astype(np.float64)
+            na = (P["grp_acc"][1:] - P["grp_acc"][:-1]).cpu().numpy()
+            for lo in range(0, ng, max(1, ng // 12)):
+                hi = min(ng, lo + max(1, ng // 12))
+                print("   part 0 groups %4d..%4d: accs/group %6.0f entries/block %8.0f stream %6.1f us -> %6.2f entries/ns/WG; zero+write %.1f us"
+                      % (lo, hi - 1, na[lo:hi].mean(), e[lo:hi].mean(), st[lo:hi].mean(), e[lo:hi].sum() / st[lo:hi].sum() / 1e3,
+                         ((t[sl, 1] - t[sl, 0]) + (t[sl, 3] - t[sl, 2]))[lo:hi].mean()), flush=True)
         del P, partial
         torch.cuda.empty_cache()
 
