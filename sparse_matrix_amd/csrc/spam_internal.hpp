@@ -134,28 +134,22 @@ struct RgKnobs {
   int k = 4;          // SPAM_SPMV_RG_K      chunks a wavefront keeps in flight
   int acc_bits = 0;   // SPAM_SPMV_RG_ABITS  cap on the accumulator bits of an entry word (0: as many as fit, at most 13)
   int fold_short = 1; // SPAM_SPMV_RG_SHORT  the short rows as blocks of the same kernel (0: spmv_short_rows_kernel)
-  int tpw = 1;        // SPAM_SPMV_RG_TPW    tiles a wavefront of the reduce kernel keeps in flight (1 / 2 / 4)
-  int prefetch = 0;   // SPAM_SPMV_RG_PREFETCH  draw a queue's next ticket while the current block streams
-  int zero_fill = 0;  // SPAM_SPMV_RG_ZERO   the reduce kernel also zeroes the empty rows instead of a zero-fill of y (measured 1 % slower)
   int prof = 0;       // SPAM_SPMV_PROF = 3   per-block phase timers, printed by every SpMV (diagnostics)
   int order_min = 32; // SPAM_SPMV_RG_ORDER  rows with fewer entries are ranked in row order (coalesced y writes), longer ones by length
 };
 struct RgPlan {
   uint32_t ng = 0, abits = 0, lds_bytes = 0, nl = 0, ntiles = 0;
-  uint32_t ord0 = 0, rows = 0;      // ranks from ord0 on are rows in ascending order
-  bool zero_by_reduce = false;      // spmv_rg_reduce_kernel also zeroes the empty rows of y
-  uint64_t* nonempty = nullptr;     // u64[(rows + 63) / 64]: rows with entries (only with zero_by_reduce)
   uint32_t ngs = 0, ns = 0;         // short-row blocks (0: no short rows, or they keep their own kernel)
-  int nt = 512, k = 4, prof = 0, tpw = 1, prefetch = 0;
+  int nt = 512, k = 4, prof = 0;
   unsigned grid = 0;
   uint64_t stream_bytes = 0, entries = 0, padded = 0, naccs = 0, npairs = 0, nonempty_blocks = 0;
   unsigned char* stream = nullptr;  // the blocks' chunks, part-major
   void* blk = nullptr;              // RgBlk[NPART * ng + ngs + 1]: block descriptors
   uint64_t* pe = nullptr;           // u64[blocks + 1]: padded entries before every block
   uint32_t* sub_head = nullptr;     // u32[naccs - npairs]: head of every extra accumulator
-  uint32_t* rank_rows = nullptr;    // u32[nl]: row of every rank
-  uint16_t* mask_rank = nullptr;    // u16[nl]: parts in which the row of a rank has a pair
-  void* tiles = nullptr;            // RgTile[ntiles]: 64 ranks of one group each
+  uint32_t* slot_rows = nullptr;    // u32[64 ntiles]: row of every rank slot (0xFFFFFFFF: none)
+  uint16_t* mask_slot = nullptr;    // u16[64 ntiles]: parts in which the row of a slot has a pair
+  void* tiles = nullptr;            // RgTile[ntiles]: 64 rank slots of one group each
   uint64_t* grp_cp = nullptr;       // u64[ng][NPART]: first pair of every (group, part) block in cp
   void* cp = nullptr;               // T[npairs]: the pair sums of one SpMV
   uint32_t* vsrc = nullptr;         // u32[padded]: source entry of every value position (spam_csr_values_changed)

@@ -705,9 +705,7 @@ static SpmvKnobs read_knobs() {
   k.rgk.fold_short = env_int("SPAM_SPMV_RG_SHORT", 1);
   k.rgk.order_min = env_int("SPAM_SPMV_RG_ORDER", k.rgk.order_min);
   k.rgk.prof = k.prof;
-  k.rgk.zero_fill = env_int("SPAM_SPMV_RG_ZERO", k.rgk.zero_fill);
-  k.rgk.tpw = env_int("SPAM_SPMV_RG_TPW", k.rgk.tpw);
-  k.rgk.prefetch = env_int("SPAM_SPMV_RG_PREFETCH", k.rgk.prefetch);
+
   return k;
 }
 
@@ -1059,7 +1057,7 @@ __global__ __launch_bounds__(256) void spmv_short_rows_kernel(const uint32_t* __
 template <class T>
 __global__ void sliced_build_tables_kernel(const T* __restrict__ x, const uint32_t* __restrict__ dest, uint32_t cols,
                                            T* __restrict__ xh, uint32_t* __restrict__ heads, T* __restrict__ y,
-                                           uint32_t rows) {  // rows = 0: y is zero-filled elsewhere (row-group reduce)
+                                           uint32_t rows) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= NPART) heads[i * HEAD_STRIDE] = 0;
   if (i < rows) y[i] = T(0);
@@ -1563,8 +1561,7 @@ template <class T>
 static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, hipStream_t s) {
   const uint32_t cols = (uint32_t)a->cols;
   const uint32_t rows = (uint32_t)a->rows;
-  const uint32_t zrows = q->rg && q->rg->zero_by_reduce ? 0u : rows;
-  sliced_build_tables_kernel<T><<<(unsigned)(((uint64_t)std::max(cols, zrows) + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, zrows);
+  sliced_build_tables_kernel<T><<<(unsigned)(((uint64_t)std::max(cols, rows) + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
   SPAM_CHECK_LAUNCH();
   // (running the short rows beside the slab kernel on a second stream was measured 3 % slower than one after the other)
   if (!(q->rg && q->rg->ngs)) SPAM_TRY(residual_run<T>(a, q, x, y, s));
@@ -1853,7 +1850,7 @@ int spam_spmv_rg_info(const spam_csr* a, int* active, uint64_t* row_groups, uint
   if (stream_bytes) *stream_bytes = g ? g->stream_bytes : 0;
   if (plan_bytes)
     *plan_bytes = g ? g->stream_bytes + g->padded * 4 + ((uint64_t)g->ng * NPART + g->ngs + 1) * 48 + (uint64_t)g->ng * NPART * 8 +
-                            (uint64_t)g->ntiles * 32 + (uint64_t)g->nl * 6 + g->npairs * 8 + (g->naccs - g->npairs) * 4
+                            (uint64_t)g->ntiles * (24 + 64 * 6) + g->npairs * 8 + (g->naccs - g->npairs) * 4
                       : 0;
   return SPAM_OK;
 }

@@ -84,16 +84,14 @@ struct RgBlk {
 };
 static_assert(sizeof(RgBlk) == 32, "RgBlk layout");
 
-// 64 consecutive ranks of one group
+// Tile t = rank slots [64 t, 64 t + 64), all of one group (a group starts on a multiple of 64: the slots skipped in
+// front of it hold no row)
 struct RgTile {
-  uint32_t row0;                // first rank
   uint32_t grp;
-  uint16_t n;                   // ranks in the tile
-  uint16_t base[SPMV_NPART];    // pairs of the group's earlier tiles, per part
-  uint16_t ordered;             // its ranks are rows in ascending order (the ranks below RgKnobs::order_min entries)
+  uint16_t base[SPMV_NPART];  // pairs of the group's earlier tiles, per part
   uint16_t pad;
 };
-static_assert(sizeof(RgTile) == 32, "RgTile layout");
+static_assert(sizeof(RgTile) == 24, "RgTile layout");
 
 template <class T>
 struct RgArgs {
@@ -108,7 +106,6 @@ struct RgArgs {
   T* y;
   const uint32_t* short_rows;
   uint32_t ngs;
-  uint32_t prefetch;          // draw the next ticket while the block streams
   unsigned long long* times;  // diagnostics (SPAM_SPMV_PROF=3): per block 4 wall-clock stamps (100 MHz); else null
 };
 
@@ -210,19 +207,16 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
   const uint32_t xcc = rg_xcc_id();
   const bool cold_first = ((blockIdx.x >> 3) & 3u) == 0u;
   int q = 0;
-  bool have = false;  // s_blk already holds this queue's next ticket (drawn while the previous block was streaming)
   for (;;) {
     uint32_t part;
     if (cold_first) part = q == 0 ? (uint32_t)SPMV_NSLAB : q == 1 ? RG_SHORT : q == 2 ? xcc : ((xcc + (uint32_t)(q - 2)) & 7u);
     else part = q == 0 ? xcc : q == 1 ? (uint32_t)SPMV_NSLAB : q == 2 ? RG_SHORT : ((xcc + (uint32_t)(q - 2)) & 7u);
-    uint32_t* qhead = P.queue + (uint64_t)SPMV_HEAD_STRIDE * part;
-    if (!have) {
-      __syncthreads();  // (everyone has read the previous ticket)
-      if (threadIdx.x == 0) s_blk = atomicAdd(qhead, 1u);
-      __syncthreads();
-    }
-    have = false;
+    // (drawing the next ticket while the block streams was measured 4 % slower: the atomic's return sits in front of
+    // wave 0's stream loads in the in-order vmcnt queue)
+    if (threadIdx.x == 0) s_blk = atomicAdd(P.queue + (uint64_t)SPMV_HEAD_STRIDE * part, 1u);
+    __syncthreads();
     const uint32_t g = __builtin_amdgcn_readfirstlane(s_blk);
+    __syncthreads();
     const bool is_short = part == RG_SHORT;
     if (g >= (is_short ? P.ngs : P.ng)) {
       if (++q > SPMV_NSLAB + 1) break;
@@ -234,9 +228,6 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
     const uint64_t off = bd->off, cp0 = bd->cp0;
     const uint32_t nheads = bd->nheads, nsubs = bd->nsubs, sub0 = bd->sub0;
     const uint32_t na = nheads + nsubs;
-    // the next ticket of this queue: in flight while the block streams, published before the block's last barrier
-    uint32_t next_ticket = 0;
-    if (P.prefetch && threadIdx.x == 0) next_ticket = atomicAdd(qhead, 1u);
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     if (P.times) t0 = wall_clock64();
     for (uint32_t i = threadIdx.x; i <= na; i += NT) acc[i] = AccT(0);  // [na] takes the padding entries
@@ -248,10 +239,6 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
       rg_stream<T, NT, K, false>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc, P.abits);
     __syncthreads();
     if (P.times) t2 = wall_clock64();
-    if (P.prefetch) {
-      if (threadIdx.x == 0) s_blk = next_ticket;
-      have = true;
-    }
     if (nsubs) {  // uniform
       for (uint32_t i = threadIdx.x; i < nsubs; i += NT) atomicAdd(&acc[P.sub_head[sub0 + i]], acc[nheads + i]);
       __syncthreads();
@@ -272,93 +259,38 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
   }
 }
 
-// y[row of rank] = sum of the row's pairs, in part order.  One wavefront per tile of 64 ranks: a row's pair in part p is
-// the (tile base + number of earlier ranks of the tile with a pair in p)-th of block (p, group).
-// The ranks from ord0 on are rows in ascending order (the rows below order_min entries): their tiles also zero the
-// EMPTY rows between two consecutive ones (and before the first / after the last), so that y needs no separate
-// zero-fill and the 8-byte stores of neighbouring lanes share their lines.  Rows that are not empty (longer rows, rows
-// of the unsliced short path) carry a bit in `nonempty` and are written by their own owner.
-// RG_TPW: tiles a wavefront of the reduce kernel keeps in flight
-template <class T, int RG_TPW>
+// y[row of rank slot] = sum of the row's pairs, in part order.  One wavefront per tile: a row's pair in part p is the
+// (tile base + number of earlier slots of the tile with a pair in p)-th of block (p, group).  The tile's descriptor, its
+// masks and its rows load side by side (the tile's first slot is 64 t), the pairs behind them: two dependent round trips
+// per wavefront, at full occupancy.
+// (Measured without gain: the tiles of the row-ordered ranks also zeroing the empty rows of their row range instead of a
+// zero-fill of y; two or four tiles per wavefront — four cost the occupancy.)
+template <class T>
 __global__ __launch_bounds__(256) void spmv_rg_reduce_kernel(const RgTile* __restrict__ tiles, uint32_t ntiles,
-                                                             const uint16_t* __restrict__ mask_rank,
-                                                             const uint32_t* __restrict__ rank_rows,
+                                                             const uint16_t* __restrict__ mask_slot,
+                                                             const uint32_t* __restrict__ slot_rows,
                                                              const uint64_t* __restrict__ grp_cp, const T* __restrict__ cp,
-                                                             T* __restrict__ y, const uint64_t* __restrict__ nonempty,
-                                                             uint32_t nl, uint32_t ord0, uint32_t rows) {
-  const uint32_t t0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * RG_TPW, lane = threadIdx.x & 63u;
-  if (t0 >= ntiles) return;
+                                                             T* __restrict__ y) {
+  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (t >= ntiles) return;
+  const uint32_t k = t * 64u + lane;
+  const RgTile tl = tiles[t];
+  const uint32_t m = mask_slot[k];  // 0 in a slot without row
+  const uint32_t r = slot_rows[k];  // RG_NONE there
   const uint64_t lt = (1ull << lane) - 1ull;
-  // every stage for all RG_TPW tiles before the next one: the tile -> mask -> pair chains of the tiles overlap
-  RgTile tl[RG_TPW];
+  const uint64_t* gc = grp_cp + (uint64_t)tl.grp * SPMV_NPART;
+  T v[SPMV_NPART];
 #pragma unroll
-  for (int j = 0; j < RG_TPW; ++j) {
-    tl[j] = tiles[min(t0 + j, ntiles - 1)];
-    if (t0 + j >= ntiles) tl[j].n = 0;
+  for (int p = 0; p < SPMV_NPART; ++p) {
+    const bool has = (m >> p) & 1u;
+    const uint64_t bal = __ballot(has);
+    const uint64_t at = gc[p] + tl.base[p] + (uint64_t)__popcll(bal & lt);
+    v[p] = has ? cp[at] : T(0);
   }
-  uint32_t m[RG_TPW], r[RG_TPW];
+  T s = v[0];
 #pragma unroll
-  for (int j = 0; j < RG_TPW; ++j) {
-    const bool act = lane < tl[j].n;
-    const uint32_t k = tl[j].row0 + lane;
-    m[j] = act ? mask_rank[k] : 0u;
-    r[j] = act ? rank_rows[k] : 0u;
-  }
-  T v[RG_TPW][SPMV_NPART];
-#pragma unroll
-  for (int j = 0; j < RG_TPW; ++j) {
-    const uint64_t* gc = grp_cp + (uint64_t)tl[j].grp * SPMV_NPART;
-#pragma unroll
-    for (int p = 0; p < SPMV_NPART; ++p) {
-      const bool has = (m[j] >> p) & 1u;
-      const uint64_t bal = __ballot(has);
-      const uint64_t at = gc[p] + tl[j].base[p] + (uint64_t)__popcll(bal & lt);
-      v[j][p] = has ? cp[at] : T(0);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < RG_TPW; ++j) {
-    T s = v[j][0];
-#pragma unroll
-    for (int p = 1; p < SPMV_NPART; ++p) s += v[j][p];
-    if (lane < tl[j].n) y[r[j]] = s;
-  }
-  if (!nonempty) return;
-  // the row range of the wavefront's ORDERED tiles (they are consecutive ranks = ascending rows): from the first one's
-  // first row (from row 0 for the first ordered tile of all) up to the first row behind the last one (the end of y for
-  // the last tile); all lanes stride over it and zero the rows without entries
-  int jf = -1, jl = -1;
-#pragma unroll
-  for (int j = 0; j < RG_TPW; ++j)
-    if (tl[j].n && tl[j].ordered) {
-      if (jf < 0) jf = j;
-      jl = j;
-    }
-  if (jf < 0) return;  // (uniform)
-  uint32_t first_row = 0, kend = 0, row0f = 0;
-#pragma unroll
-  for (int j = 0; j < RG_TPW; ++j) {
-    if (j == jf) first_row = __shfl(r[j], 0, 64), row0f = tl[j].row0;
-    if (j == jl) kend = tl[j].row0 + tl[j].n;
-  }
-  const uint32_t lo = row0f == ord0 ? 0u : first_row;
-  const uint32_t hi = kend < nl ? rank_rows[kend] : rows;
-  for (uint32_t w0 = lo >> 6; (uint64_t)w0 * 64 < hi; w0 += 64) {  // 64 bitmap words = 4096 rows per pass
-    const uint32_t nw = min(64u, (hi + 63u) / 64u - w0);
-    const uint64_t myw = lane < nw ? nonempty[w0 + lane] : ~0ull;
-    for (uint32_t i = 0; i < nw; ++i) {
-      const uint64_t w = __shfl(myw, (int)i, 64);
-      const uint32_t q = (w0 + i) * 64u + lane;
-      if (q >= lo && q < hi && !((w >> lane) & 1ull)) y[q] = T(0);
-    }
-  }
-}
-
-__global__ void rg_nonempty_kernel(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint64_t* __restrict__ nonempty) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (whole wavefronts: rows rounded up to 64 by the grid)
-  const bool ne = r < rows && row_ptr[r + 1] > row_ptr[r];
-  const uint64_t bal = __ballot(ne);
-  if ((threadIdx.x & 63) == 0 && r < rows) nonempty[r >> 6] = bal;
+  for (int p = 1; p < SPMV_NPART; ++p) s += v[p];
+  if (r != RG_NONE) y[r] = s;
 }
 
 // ---- plan construction ------------------------------------------------------------------------------------------
@@ -385,32 +317,38 @@ __global__ void rg_row_kernel(const uint32_t* __restrict__ row_ptr, const uint32
     mask[w] = (uint16_t)m;
   }
 }
-__global__ void rg_rank_kernel(const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ idx_of_rank,
-                               const uint16_t* __restrict__ mask, const uint32_t* __restrict__ len, uint32_t nl,
-                               uint32_t* __restrict__ rank_rows, uint32_t* __restrict__ rank_of,
-                               uint16_t* __restrict__ mask_rank, uint32_t* __restrict__ len_rank) {
+__global__ void rg_rank_kernel(const uint32_t* __restrict__ idx_of_rank, const uint16_t* __restrict__ mask,
+                               const uint32_t* __restrict__ len, uint32_t nl, uint16_t* __restrict__ mask_rank,
+                               uint32_t* __restrict__ len_rank) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nl) return;
   const uint32_t i = idx_of_rank[k];
-  rank_rows[k] = long_rows[i];
-  rank_of[i] = k;
   mask_rank[k] = mask[i];
   len_rank[k] = len[i];
 }
-// One wavefront per tile: the head accumulator of every (rank, part) pair inside its block.
-__global__ void rg_hidx_kernel(const RgTile* __restrict__ tiles, uint32_t ntiles, const uint16_t* __restrict__ mask_rank,
+// rank -> slot: the row of every slot and the slot of every sliced row
+__global__ void rg_slot_kernel(const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ idx_of_rank,
+                               const uint32_t* __restrict__ slot_of_rank, uint32_t nl, uint32_t* __restrict__ slot_rows,
+                               uint32_t* __restrict__ slot_of) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nl) return;
+  const uint32_t i = idx_of_rank[k], sl = slot_of_rank[k];
+  slot_rows[sl] = long_rows[i];
+  slot_of[i] = sl;
+}
+// One wavefront per tile: the head accumulator of every (slot, part) pair inside its block.
+__global__ void rg_hidx_kernel(const RgTile* __restrict__ tiles, uint32_t ntiles, const uint16_t* __restrict__ mask_slot,
                                uint16_t* __restrict__ hidx) {
   const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (t >= ntiles) return;
   const RgTile tl = tiles[t];
-  const bool act = lane < tl.n;
-  const uint32_t k = tl.row0 + lane;
-  const uint32_t m = act ? mask_rank[k] : 0u;
+  const uint32_t k = t * 64u + lane;
+  const uint32_t m = mask_slot[k];
   const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int p = 0; p < SPMV_NPART; ++p) {
     const uint64_t bal = __ballot((m >> p) & 1u);
-    if (act) hidx[(uint64_t)k * SPMV_NPART + p] = (uint16_t)(tl.base[p] + (uint32_t)__popcll(bal & lt));
+    hidx[(uint64_t)k * SPMV_NPART + p] = (uint16_t)(tl.base[p] + (uint32_t)__popcll(bal & lt));
   }
 }
 
@@ -427,7 +365,7 @@ __global__ void rg_keys_kernel(const uint32_t* __restrict__ row_ptr, const uint3
   if (w >= nl) return;
   const uint32_t r = long_rows[w];
   const uint32_t s = row_ptr[r], e = row_ptr[r + 1];
-  const uint32_t k = rank_of[w];
+  const uint32_t k = rank_of[w];  // (its rank slot)
   const uint32_t g = rk_grp[k], rs = rk_sub[k];
   const uint32_t nsub = rs >> 16, sofs = rs & 0xFFFFu;  // accumulators of the row in a block: its head and nsub - 1 extra
   const uint64_t o = lofs[w];
@@ -576,15 +514,15 @@ static int rg_dispatch(const RgPlan* g, const RgArgs<T>* args, hipStream_t s, un
 struct RgGroup {
   uint32_t heads[SPMV_NPART];
   uint32_t nsubs;
-  uint32_t first_rank;
-  std::vector<uint32_t> sub_rank, sub_cnt;  // ranks with extra accumulators, and how many
+  uint32_t first_slot;
+  std::vector<uint32_t> sub_slot, sub_cnt;  // slots of the rows with extra accumulators, and how many
 };
 
 }  // namespace
 
 void rg_plan_free(RgPlan* g) {
   if (!g) return;
-  void* ptrs[] = {g->stream, g->blk, g->pe, g->sub_head, g->rank_rows, g->mask_rank, g->tiles, g->grp_cp, g->cp, g->vsrc, g->nonempty};
+  void* ptrs[] = {g->stream, g->blk, g->pe, g->sub_head, g->slot_rows, g->mask_slot, g->tiles, g->grp_cp, g->cp, g->vsrc};
   for (void* p : ptrs)
     if (p) dev_free(p);
   delete g;
@@ -624,12 +562,9 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_TRY(tmp.alloc(tb));
   SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key_in.as<uint32_t>(), key_out.as<uint32_t>(), idx_in.as<uint32_t>(),
                                                   idx_out.as<uint32_t>(), (int64_t)nl, 0, 32, s));
-  DevBuf rank_rows, rank_of, mask_rank;
-  SPAM_TRY(rank_rows.alloc((uint64_t)nl * 4));
-  SPAM_TRY(rank_of.alloc((uint64_t)nl * 4));
+  DevBuf mask_rank;
   SPAM_TRY(mask_rank.alloc((uint64_t)nl * 2 + 2));
-  rg_rank_kernel<<<gl, 256, 0, s>>>(long_rows, idx_out.as<uint32_t>(), mask.as<uint16_t>(), len.as<uint32_t>(), nl,
-                                    rank_rows.as<uint32_t>(), rank_of.as<uint32_t>(), mask_rank.as<uint16_t>(),
+  rg_rank_kernel<<<gl, 256, 0, s>>>(idx_out.as<uint32_t>(), mask.as<uint16_t>(), len.as<uint32_t>(), nl, mask_rank.as<uint16_t>(),
                                     key_in.as<uint32_t>() /* reused: lengths in rank order */);
   SPAM_CHECK_LAUNCH();
   std::vector<uint32_t> h_len(nl);
@@ -645,36 +580,27 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (n_ent == 0 || n_ent >= 0xFFFFFFFFull) return SPAM_OK;
 
-  // ranks from ord0 on are the rows below order_min entries, in row order (rg_row_kernel's sort key)
-  uint32_t ord0 = nl;
-  {
-    const uint32_t om = (uint32_t)std::max(1, kn.order_min);
-    uint32_t lo = 0, hi = nl;  // lengths are non-increasing up to ord0; first rank with len < om
-    while (lo < hi) {
-      const uint32_t mid = lo + (hi - lo) / 2;
-      if (h_len[mid] < om) hi = mid;
-      else lo = mid + 1;
-    }
-    ord0 = lo;
-  }
-  // -- row groups and tiles (host): consecutive ranks; per part at most rmax accumulators, ecap entries in all ----------
-  std::vector<uint32_t> h_grp(nl), h_rsub(nl), h_sub_head;
+  // -- row groups and tiles (host): consecutive ranks; per part at most rmax accumulators, ecap entries in all.  Ranks
+  //    are placed in SLOTS: a group starts on a multiple of 64 slots, so that tile t is slots [64 t, 64 t + 64) ----------
+  std::vector<uint32_t> h_slot(nl), h_sub_head;
+  std::vector<uint32_t> h_grp_s, h_rsub_s;   // by slot
+  std::vector<uint16_t> h_mask_s;            // by slot (0 in a slot without row)
   std::vector<RgTile> h_tiles;
   std::vector<RgGroup> groups;
   {
     RgGroup cur{};
     uint64_t ents = 0;
-    uint32_t in_tile = 0;
-    auto open_tile = [&](uint32_t k) {
+    uint32_t slot = 0;
+    auto open_tile = [&]() {
       RgTile t{};
-      t.row0 = k, t.grp = (uint32_t)groups.size(), t.n = 0, t.ordered = k >= ord0;
+      t.grp = (uint32_t)groups.size();
       for (int p = 0; p < SPMV_NPART; ++p) t.base[p] = (uint16_t)cur.heads[p];
       h_tiles.push_back(t);
-      in_tile = 0;
+      h_grp_s.resize((size_t)h_tiles.size() * 64, 0u), h_rsub_s.resize((size_t)h_tiles.size() * 64, 0u);
+      h_mask_s.resize((size_t)h_tiles.size() * 64, (uint16_t)0);
     };
-    open_tile(0);
+    open_tile();
     for (uint32_t k = 0; k < nl; ++k) {
-      const bool ord_start = k == ord0 && k > 0;  // the row-ordered ranks start a tile of their own
       const uint64_t L = h_len[k];
       // a row holding the fraction f of a block's entries draws 64 f lanes of every wave instruction: 8 x as many
       // accumulators keep two lanes off one LDS address most of the time
@@ -687,23 +613,31 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
       if (worst + cur.nsubs + (nsub - 1) > rmax || (ents > 0 && ents + L > ecap)) {
         groups.push_back(cur);
         cur = RgGroup{};
-        cur.first_rank = k;
         ents = 0;
-        open_tile(k);
-      } else if (in_tile == 64 || ord_start) {
-        open_tile(k);
+        slot = (slot + 63u) & ~63u;
+        if (slot == (uint32_t)h_tiles.size() * 64u) open_tile();
+        else {  // (the group before ended exactly on a tile boundary and no tile was opened for this slot yet)
+          h_tiles.back().grp = (uint32_t)groups.size();
+          for (int p = 0; p < SPMV_NPART; ++p) h_tiles.back().base[p] = 0;
+        }
+        cur.first_slot = slot;
+      } else if (slot == (uint32_t)h_tiles.size() * 64u) {
+        open_tile();
       }
-      h_grp[k] = (uint32_t)groups.size();
-      h_rsub[k] = cur.nsubs | ((uint32_t)nsub << 16);
-      if (nsub > 1) cur.sub_rank.push_back(k), cur.sub_cnt.push_back((uint32_t)nsub - 1), cur.nsubs += (uint32_t)nsub - 1;
+      h_slot[k] = slot;
+      h_grp_s[slot] = (uint32_t)groups.size();
+      h_rsub_s[slot] = cur.nsubs | ((uint32_t)nsub << 16);
+      h_mask_s[slot] = (uint16_t)m;
+      if (nsub > 1) cur.sub_slot.push_back(slot), cur.sub_cnt.push_back((uint32_t)nsub - 1), cur.nsubs += (uint32_t)nsub - 1;
       for (int p = 0; p < SPMV_NPART; ++p) cur.heads[p] += (m >> p) & 1u;
       ents += L;
-      h_tiles.back().n = (uint16_t)(++in_tile);
+      ++slot;
     }
     groups.push_back(cur);
   }
   const uint32_t ng = (uint32_t)groups.size();
   const uint32_t ntiles = (uint32_t)h_tiles.size();
+  const uint64_t nslots = (uint64_t)ntiles * 64;
   // short rows (the residual CSR, compacted by the caller): groups of rmax consecutive rows behind the nine parts
   const bool fold = kn.fold_short && res && ns > 0 && res->nnz > 0;
   const uint32_t srows = rmax;
@@ -738,12 +672,12 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
       h_blk[(size_t)p * ng + gi].sub0 = (uint32_t)h_sub_head.size();
       size_t si = 0;
       uint32_t c = 0;  // pairs of part p among the group's ranks before k (the rule of rg_hidx_kernel)
-      for (uint32_t k = G.first_rank; si < G.sub_rank.size(); ++k) {
-        if (k == G.sub_rank[si]) {
+      for (uint32_t sl = G.first_slot; si < G.sub_slot.size(); ++sl) {
+        if (sl == G.sub_slot[si]) {
           for (uint32_t j = 0; j < G.sub_cnt[si]; ++j) h_sub_head.push_back(c);
           ++si;
         }
-        c += (h_mask[k] >> p) & 1u;
+        c += (h_mask_s[sl] >> p) & 1u;
       }
     }
   }
@@ -756,30 +690,31 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   } guard{g};
   g->ng = ng, g->abits = (uint32_t)abits, g->entries = n_ent + n_short, g->npairs = npairs, g->ntiles = ntiles, g->nl = nl;
   g->ngs = ngs, g->ns = fold ? ns : 0;
-  g->ord0 = ord0, g->rows = (uint32_t)a->rows, g->zero_by_reduce = kn.zero_fill && ord0 < nl;
-  g->nt = kn.nt, g->k = kn.k, g->prof = kn.prof, g->tpw = kn.tpw, g->prefetch = kn.prefetch;
+  g->nt = kn.nt, g->k = kn.k, g->prof = kn.prof;
   g->lds_bytes = (rmax + 1u) * 8u;
   g->naccs = npairs + h_sub_head.size();
 
-  DevBuf ne_bits;
-  if (g->zero_by_reduce) {
-    const uint64_t words = ((uint64_t)a->rows + 63) / 64;
-    SPAM_TRY(ne_bits.alloc(words * 8));
-    rg_nonempty_kernel<<<(unsigned)((words * 64 + 255) / 256), 256, 0, s>>>(a->row_ptr32, (uint32_t)a->rows, ne_bits.as<uint64_t>());
-    SPAM_CHECK_LAUNCH();
-  }
-  DevBuf rk_grp, rk_sub, tiles, hidx, blk;
-  SPAM_TRY(rk_grp.alloc((uint64_t)nl * 4));
-  SPAM_TRY(rk_sub.alloc((uint64_t)nl * 4));
+  DevBuf rk_grp, rk_sub, tiles, hidx, blk, slot_of_rank, slot_rows, slot_of, mask_slot;
+  SPAM_TRY(rk_grp.alloc(nslots * 4));
+  SPAM_TRY(rk_sub.alloc(nslots * 4));
   SPAM_TRY(tiles.alloc((uint64_t)ntiles * sizeof(RgTile)));
-  SPAM_TRY(hidx.alloc((uint64_t)nl * SPMV_NPART * 2));
+  SPAM_TRY(hidx.alloc(nslots * SPMV_NPART * 2));
   SPAM_TRY(blk.alloc(((uint64_t)nb + 1) * sizeof(RgBlk)));
-  SPAM_HIP_TRY(hipMemcpyAsync(rk_grp.p, h_grp.data(), (uint64_t)nl * 4, hipMemcpyHostToDevice, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(rk_sub.p, h_rsub.data(), (uint64_t)nl * 4, hipMemcpyHostToDevice, s));
+  SPAM_TRY(slot_of_rank.alloc((uint64_t)nl * 4));
+  SPAM_TRY(slot_rows.alloc(nslots * 4));
+  SPAM_TRY(slot_of.alloc((uint64_t)nl * 4));
+  SPAM_TRY(mask_slot.alloc(nslots * 2));
+  SPAM_HIP_TRY(hipMemcpyAsync(rk_grp.p, h_grp_s.data(), nslots * 4, hipMemcpyHostToDevice, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(rk_sub.p, h_rsub_s.data(), nslots * 4, hipMemcpyHostToDevice, s));
   SPAM_HIP_TRY(hipMemcpyAsync(tiles.p, h_tiles.data(), (uint64_t)ntiles * sizeof(RgTile), hipMemcpyHostToDevice, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(mask_rank.p, h_mask.data(), (uint64_t)nl * 2, hipMemcpyHostToDevice, s));  // (forced masks)
+  SPAM_HIP_TRY(hipMemcpyAsync(mask_slot.p, h_mask_s.data(), nslots * 2, hipMemcpyHostToDevice, s));  // (with the forced masks)
+  SPAM_HIP_TRY(hipMemcpyAsync(slot_of_rank.p, h_slot.data(), (uint64_t)nl * 4, hipMemcpyHostToDevice, s));
   SPAM_HIP_TRY(hipMemcpyAsync(blk.p, h_blk.data(), ((uint64_t)nb + 1) * sizeof(RgBlk), hipMemcpyHostToDevice, s));
-  rg_hidx_kernel<<<(ntiles + 3) / 4, 256, 0, s>>>(tiles.as<RgTile>(), ntiles, mask_rank.as<uint16_t>(), hidx.as<uint16_t>());
+  SPAM_HIP_TRY(hipMemsetAsync(slot_rows.p, 0xFF, nslots * 4, s));  // RG_NONE in the slots without row
+  rg_slot_kernel<<<gl, 256, 0, s>>>(long_rows, idx_out.as<uint32_t>(), slot_of_rank.as<uint32_t>(), nl, slot_rows.as<uint32_t>(),
+                                    slot_of.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  rg_hidx_kernel<<<(ntiles + 3) / 4, 256, 0, s>>>(tiles.as<RgTile>(), ntiles, mask_slot.as<uint16_t>(), hidx.as<uint16_t>());
   SPAM_CHECK_LAUNCH();
 
   // -- entries: key, sort by (block, slot) -------------------------------------------------------------------------------
@@ -789,7 +724,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_TRY(keys_out.alloc(n_all * 8));
   SPAM_TRY(src_in.alloc(n_all * 4));
   SPAM_TRY(src_out.alloc(n_all * 4));
-  rg_keys_kernel<<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, code, slab, long_rows, nl, lofs.as<uint64_t>(), rank_of.as<uint32_t>(),
+  rg_keys_kernel<<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, code, slab, long_rows, nl, lofs.as<uint64_t>(), slot_of.as<uint32_t>(),
                                     rk_grp.as<uint32_t>(), rk_sub.as<uint32_t>(), hidx.as<uint16_t>(), blk.as<RgBlk>(), ng,
                                     keys_in.as<uint64_t>(), src_in.as<uint32_t>());
   SPAM_CHECK_LAUNCH();
@@ -856,13 +791,12 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   g->blk = blk.release();
   g->pe = pe.as<uint64_t>(), pe.release();
   g->sub_head = sub_head.as<uint32_t>(), sub_head.release();
-  g->rank_rows = rank_rows.as<uint32_t>(), rank_rows.release();
-  g->mask_rank = mask_rank.as<uint16_t>(), mask_rank.release();
+  g->slot_rows = slot_rows.as<uint32_t>(), slot_rows.release();
+  g->mask_slot = mask_slot.as<uint16_t>(), mask_slot.release();
   g->tiles = tiles.release();
   g->grp_cp = grp_cp.as<uint64_t>(), grp_cp.release();
   g->cp = cp.release();
   g->vsrc = vsrc.as<uint32_t>(), vsrc.release();
-  g->nonempty = (uint64_t*)ne_bits.release();
   RgArgs<T> none{};
   SPAM_TRY(rg_dispatch<T>(g, &none, s, &g->grid));
   guard.g = nullptr;
@@ -879,7 +813,7 @@ int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, uint32_t* queue
   P.base[SPMV_NSLAB] = x;
   P.cp = (T*)g->cp, P.queue = queue, P.ng = g->ng, P.abits = g->abits;
   P.y = y, P.short_rows = short_rows, P.ngs = g->ngs;
-  P.times = nullptr, P.prefetch = (uint32_t)g->prefetch;
+  P.times = nullptr;
   DevBuf tbuf;
   const uint64_t nblk = (uint64_t)g->ng * SPMV_NPART + g->ngs;
   if (g->prof == 3) {  // diagnostics: where the workgroups' time goes (one synchronous launch, stderr)
@@ -915,14 +849,8 @@ int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, uint32_t* queue
       if (last) fprintf(stderr, "[spam]   part %d: last block ends at %.1f us, stream time summed %.0f us\n", p, (double)(last - lo) / 100.0, st / 100.0);
     }
   }
-#define SPAM_RG_REDUCE(TPW_)                                                                                          \
-  spmv_rg_reduce_kernel<T, TPW_><<<(g->ntiles + 4 * TPW_ - 1) / (4 * TPW_), 256, 0, s>>>(                              \
-      (const RgTile*)g->tiles, g->ntiles, g->mask_rank, g->rank_rows, g->grp_cp, (const T*)g->cp, y,                    \
-      g->zero_by_reduce ? g->nonempty : nullptr, g->nl, g->ord0, g->rows)
-  if (g->tpw >= 4) SPAM_RG_REDUCE(4);
-  else if (g->tpw == 2) SPAM_RG_REDUCE(2);
-  else SPAM_RG_REDUCE(1);
-#undef SPAM_RG_REDUCE
+  spmv_rg_reduce_kernel<T><<<(g->ntiles + 3) / 4, 256, 0, s>>>((const RgTile*)g->tiles, g->ntiles, g->mask_slot, g->slot_rows,
+                                                              g->grp_cp, (const T*)g->cp, y);
   SPAM_CHECK_LAUNCH();
   return SPAM_OK;
 }

@@ -22,8 +22,7 @@ F32_RTOL = 3e-5
 
 ENV_KEYS = ("SPAM_SPMV_SLICED", "SPAM_SPMV_SLICE_KB", "SPAM_SPMV_LDS_KB", "SPAM_SPMV_LONG", "SPAM_SPMV_SLICED_TPB",
             "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS", "SPAM_SPMV_L0_KB", "SPAM_SPMV_PIPE", "SPAM_SPMV_RG",
-            "SPAM_SPMV_RG_EBLK", "SPAM_SPMV_RG_NT", "SPAM_SPMV_RG_K", "SPAM_SPMV_RG_ABITS", "SPAM_SPMV_RG_SHORT", "SPAM_SPMV_RG_ORDER", "SPAM_SPMV_RG_ZERO", "SPAM_SPMV_RG_TPW",
-            "SPAM_SPMV_RG_PREFETCH")
+            "SPAM_SPMV_RG_EBLK", "SPAM_SPMV_RG_NT", "SPAM_SPMV_RG_K", "SPAM_SPMV_RG_ABITS", "SPAM_SPMV_RG_SHORT", "SPAM_SPMV_RG_ORDER")
 
 
 @pytest.fixture(params=[1, 0], ids=["rowgroups", "tiles"])
@@ -198,14 +197,12 @@ def test_row_block_view_forced(spam, oracle, sliced_env):
 @pytest.mark.parametrize("cfg", [dict(RG_EBLK=1024), dict(RG_EBLK=1024, RG_ABITS=9), dict(RG_ABITS=10, RG_NT=1024, RG_K=2),
                                  dict(RG_EBLK=4096, RG_NT=256), dict(RG_EBLK=2048, RG_NT=1024, RG_K=4, LONG=1),
                                  dict(RG_EBLK=1024, RG_SHORT=0, LONG=9), dict(RG_ABITS=9, LONG=40), dict(RG_EBLK=1024, LONG=7),
-                                 dict(RG_ZERO=1), dict(RG_ZERO=1, RG_TPW=4, RG_ORDER=1000), dict(RG_TPW=2, RG_ORDER=1),
-                                 dict(RG_PREFETCH=1, RG_EBLK=1024), dict(RG_ZERO=1, RG_ORDER=4, LONG=3)])
+                                 dict(RG_ORDER=1000, RG_EBLK=4096), dict(RG_ORDER=1), dict(RG_ORDER=4, LONG=3, RG_EBLK=1024)])
 @pytest.mark.parametrize("kind", ["rmat14", "powerlaw"])
 def test_row_groups_geometries(spam, oracle, sliced_env, cfg, kind):
     """Small blocks (many groups, rows with several accumulators each), narrow accumulator fields (511 / 1023 pairs per
     block), every kernel geometry; the hub rows of the power-law matrix take the folded sub-accumulators; short rows
-    as blocks of the same kernel (LONG > 1) or in their own kernel (RG_SHORT=0); the reduce kernel zeroing the empty
-    rows (RG_ZERO), several tiles per wavefront, all ranks by length / in row order; ticket prefetch."""
+    as blocks of the same kernel (LONG > 1) or in their own kernel (RG_SHORT=0); all ranks in row order / by length."""
     sliced_env(SLICE_KB=8, **cfg)
     if os.environ["SPAM_SPMV_RG"] != "1":
         pytest.skip("row-group knobs")
