@@ -271,7 +271,9 @@ __global__ __launch_bounds__(256) void spmv_rg_reduce_kernel(const RgTile* __res
                                                              const uint32_t* __restrict__ slot_rows,
                                                              const uint64_t* __restrict__ grp_cp, const T* __restrict__ cp,
                                                              T* __restrict__ y) {
-  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  // (the tile index is wave-uniform: as a scalar, the descriptor and the nine block bases are scalar loads and leave the
+  // vector-memory pipeline to the masks, rows, pairs and the store)
+  const uint32_t t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), lane = threadIdx.x & 63u;
   if (t >= ntiles) return;
   const uint32_t k = t * 64u + lane;
   const RgTile tl = tiles[t];
