@@ -1589,7 +1589,7 @@ static int plain_run(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, h
   const int npt = p->npt;
   const uint32_t tile = SPMV_TPB * npt;
   const unsigned grid = (unsigned)p->ntiles;
-  const int hot = p->hot_k ? hot_cfg : 0;
+  const int hot = p->hot_k && p->ja_hot ? hot_cfg : 0;
   const uint32_t* col = hot ? p->ja_hot : a->col_idx;
   const T* val = (const T*)a->vals;
   const T* xh = (const T*)p->xh;
@@ -1751,6 +1751,13 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
       }
     }
     p->sliced = q;
+    if (q) {  // the plain path's hot-column table (4 bytes per entry) is not read again on this handle
+      SPAM_HIP_TRY(hipStreamSynchronize(s));
+      if (p->ja_hot) dev_free(p->ja_hot);
+      if (p->hot_cols) dev_free(p->hot_cols);
+      if (p->xh) dev_free(p->xh);
+      p->ja_hot = nullptr, p->hot_cols = nullptr, p->xh = nullptr;  // (hot_k / hot_cover stay for spam_spmv_plan_info)
+    }
   }
   p->prepared = true;
   guard.p = nullptr;

@@ -5,16 +5,17 @@
 // kept each part as a CSR over the sliced rows and summed rows tile by tile: the x gathers of a tile go to unrelated
 // table lines, every lane costs the L2 one request, and 245 G requests/s bound the kernel (0.78 ms for 154 M entries).
 //
-// This form turns the part around.  The sliced rows are ranked by length and cut into ROW GROUPS; a BLOCK is
-// (part, row group):
+// This form turns the part around.  The sliced rows are ranked (32 entries and more: by length, descending; the others
+// behind them in row order) and cut into ROW GROUPS; a BLOCK is (part, row group):
 //   * the block's accumulators live in LDS (8 bytes each: f64 for f32 / f64 values, u64 for i64), one per (row, part)
 //     PAIR that exists — a row without entries in the part has none, so short rows cost what they hold;
 //   * the block's entries are stored in TABLE-SLOT order, 256-entry chunks, each entry one 32-bit word
 //     (slot << abits | accumulator) and its value: a wave instruction gathers 64 consecutive slots — a handful of
 //     128-byte lines that the CU's L1 serves — and adds its products with LDS atomics (ds_add_f64 / ds_add_u64);
 //   * the block stores its sums as one contiguous run of the pair array `cp` (pairs of a block in rank order);
-//   * spmv_rg_reduce_kernel, one wavefront per 64 ranks, finds a row's pair in every part from the row's part mask
-//     (position = tile base + ballot prefix), adds them in part order and writes y[row of that rank].
+//   * spmv_rg_reduce_kernel, one wavefront per TILE of 64 rank slots (a group starts on a multiple of 64 slots), finds
+//     a row's pair in every part from the row's part mask (position = tile base + ballot prefix), adds them in part
+//     order and writes y[row].
 // Rows that would draw most lanes of a wave instruction to one LDS address get extra accumulators behind the block's
 // heads (an entry picks one by its position in the row); they are folded into their head before the sums are stored.
 // Rows below the sliced-row threshold (none by default) join as a tenth kind of block: consecutive short rows, all
