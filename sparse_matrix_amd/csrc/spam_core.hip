@@ -11,6 +11,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <time.h>
+
 #include "spam_internal.hpp"
 
 namespace spam {
@@ -28,6 +30,12 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 void clear_error() { g_err.clear(); }
+double PhaseClock::now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 hipStream_t stream() { return g_stream; }
 
 // ---- caching device allocator ---------------------------------------------------------------------

@@ -41,6 +41,22 @@ void clear_error();
 
 hipStream_t stream();
 
+// Diagnostics (SPAM_SPMV_PROF=4): wall-clock stamps of the analysis phases, each after a stream synchronise.
+struct PhaseClock {
+  bool on;
+  hipStream_t s;
+  double t0;
+  static double now();
+  PhaseClock(bool on_, hipStream_t s_) : on(on_), s(s_), t0(on_ ? now() : 0.0) {}
+  void stamp(const char* what) {
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    const double t = now();
+    fprintf(stderr, "[spam] prepare: %-44s %8.2f ms\n", what, (t - t0) * 1e3);
+    t0 = t;
+  }
+};
+
 // Caching device allocator: freed blocks are kept and handed back to later requests of a similar size, so a
 // product repeated on same-sized operands pays hipMalloc (seconds for a 100 GB C) only once — the same
 // steady state the reference's Vec::with_capacity gets from the process allocator (mul_hash.rs:119).
@@ -116,6 +132,9 @@ int scan_u32_to_u64(const uint32_t* d_in, uint64_t n, uint64_t* d_out, void* d_t
 int scan_u64_to_u64(const uint64_t* d_in, uint64_t n, uint64_t* d_out, void* d_tmp, hipStream_t s);
 // *d_flag |= 1 if any partial sum wrapped (checked_add overflow)
 int narrow_row_ptr(const uint64_t* d_in, uint64_t n, uint32_t* d_out, hipStream_t s);
+
+// d_out = d_in sorted in descending order (hipCUB radix sort; spam_spmv_rg.hip)
+int sort_u32_desc(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t s);
 
 // ---- SpMV (spam_spmv.hip) ------------------------------------------------------------------------
 void spmv_plan_free(SpmvPlan* p);

@@ -617,37 +617,64 @@ __global__ void xh_build_kernel(const T* __restrict__ x, const uint32_t* __restr
 
 // Decide the hot set: the largest threshold t whose columns {cnt >= t} fit the table budget.  Disabled when x
 // fits the budget anyway, when cols >= 2^31 (no spare bit), or when the hot set covers < 40 % of the gathers.
+// Column reference counts of a matrix and the same counts in descending order: computed once per analysis and shared by
+// the hot-column table of the plain path and the slab tables of the sliced one.
+struct ColStats {
+  DevBuf cnt, sorted, out;
+  uint32_t cols = 0;
+};
+static int col_stats(const spam_csr* a, ColStats* cs, hipStream_t s) {
+  cs->cols = (uint32_t)a->cols;
+  SPAM_TRY(cs->cnt.alloc((uint64_t)cs->cols * 4));
+  SPAM_TRY(cs->sorted.alloc((uint64_t)cs->cols * 4));
+  SPAM_TRY(cs->out.alloc(16));
+  SPAM_HIP_TRY(hipMemsetAsync(cs->cnt.p, 0, (uint64_t)cs->cols * 4, s));
+  col_count_kernel<<<8192, 256, 0, s>>>(a->col_idx, a->nnz, cs->cnt.as<uint32_t>());
+  SPAM_CHECK_LAUNCH();
+  return sort_u32_desc(cs->cnt.as<uint32_t>(), cs->sorted.as<uint32_t>(), cs->cols, s);
+}
+// Smallest threshold t >= 1 whose column set {cnt >= t} has at most kmax members (= the (kmax + 1)-th largest count + 1);
+// n = their number, mass = their total count.  Two small device reads instead of a 31-step bisection.
+static int threshold_from_sorted(const ColStats* cs, uint64_t kmax, hipStream_t s, uint32_t* t_out, uint64_t* n_out,
+                                 uint64_t* mass_out) {
+  uint32_t t = 1;
+  if (kmax < cs->cols) {
+    uint32_t v = 0;
+    SPAM_HIP_TRY(hipMemcpyAsync(&v, cs->sorted.as<uint32_t>() + kmax, 4, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipStreamSynchronize(s));
+    t = v + 1u;
+  }
+  unsigned long long h[2] = {0, 0};
+  SPAM_HIP_TRY(hipMemsetAsync(cs->out.p, 0, 16, s));
+  const unsigned g = (unsigned)std::min<uint64_t>(((uint64_t)cs->cols + 255) / 256, 4096);
+  count_ge_kernel<<<g, 256, 0, s>>>(cs->cnt.as<uint32_t>(), cs->cols, t, cs->out.as<unsigned long long>());
+  SPAM_CHECK_LAUNCH();
+  SPAM_HIP_TRY(hipMemcpyAsync(h, cs->out.p, 16, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  *t_out = t, *n_out = h[0], *mass_out = h[1];
+  return SPAM_OK;
+}
+
 template <class T>
-static int spmv_hot_analyse(const spam_csr* a, SpmvPlan* p, int hot_kb, hipStream_t s) {
+static int spmv_hot_analyse(const spam_csr* a, SpmvPlan* p, int hot_kb, hipStream_t s, const ColStats* shared = nullptr) {
   p->hot_kb = hot_kb;
   p->hot_k = 0;
   const uint64_t kmax = (uint64_t)hot_kb * 1024 / sizeof(T);
   if (hot_kb <= 0 || a->cols >= HOT_BIT || a->cols <= 2 * kmax || a->nnz == 0) return SPAM_OK;
   const uint32_t cols = (uint32_t)a->cols;
-  DevBuf cnt, out, flag, pos, tmp, slot;
-  SPAM_TRY(cnt.alloc((uint64_t)cols * 4));
-  SPAM_TRY(out.alloc(16));
-  SPAM_HIP_TRY(hipMemsetAsync(cnt.p, 0, (uint64_t)cols * 4, s));
-  col_count_kernel<<<8192, 256, 0, s>>>(a->col_idx, a->nnz, cnt.as<uint32_t>());
-  SPAM_CHECK_LAUNCH();
-  // bisect t in [1, 2^31): count(t) is non-increasing; want the smallest t with count(t) <= kmax
-  uint32_t lo = 1, hi = 0x7FFFFFFFu;
+  ColStats own;
+  if (!shared) {
+    SPAM_TRY(col_stats(a, &own, s));
+    shared = &own;
+  }
+  const DevBuf& cnt = shared->cnt;
+  DevBuf flag, pos, tmp, slot;
+  uint32_t lo = 1;
   unsigned long long best[2] = {0, 0};
-  const unsigned g = (unsigned)std::min<uint64_t>((cols + 255) / 256, 4096);
-  while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    unsigned long long h[2];
-    SPAM_HIP_TRY(hipMemsetAsync(out.p, 0, 16, s));
-    count_ge_kernel<<<g, 256, 0, s>>>(cnt.as<uint32_t>(), cols, mid, out.as<unsigned long long>());
-    SPAM_CHECK_LAUNCH();
-    SPAM_HIP_TRY(hipMemcpyAsync(h, out.p, 16, hipMemcpyDeviceToHost, s));
-    SPAM_HIP_TRY(hipStreamSynchronize(s));
-    if (h[0] <= kmax) {
-      hi = mid;
-      best[0] = h[0], best[1] = h[1];
-    } else {
-      lo = mid + 1;
-    }
+  {
+    uint64_t n = 0, mass = 0;
+    SPAM_TRY(threshold_from_sorted(shared, kmax, s, &lo, &n, &mass));
+    best[0] = n, best[1] = mass;
   }
   const uint32_t t = lo;
   if (best[0] == 0 || (double)best[1] < 0.40 * (double)a->nnz) return SPAM_OK;
@@ -707,35 +734,6 @@ static SpmvKnobs read_knobs() {
   k.rgk.prof = k.prof;
 
   return k;
-}
-
-// Smallest threshold t whose column set {cnt >= t} has at most kmax members; n = their number, mass = their total count.
-static int bisect_threshold(const uint32_t* cnt, uint32_t cols, uint64_t kmax, hipStream_t s, uint32_t* t_out,
-                            uint64_t* n_out, uint64_t* mass_out) {
-  DevBuf out;
-  SPAM_TRY(out.alloc(16));
-  uint32_t lo = 1, hi = 0x7FFFFFFFu;
-  unsigned long long best[2] = {0, 0};
-  const unsigned g = (unsigned)std::min<uint64_t>((cols + 255) / 256, 4096);
-  while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    unsigned long long h[2];
-    SPAM_HIP_TRY(hipMemsetAsync(out.p, 0, 16, s));
-    count_ge_kernel<<<g, 256, 0, s>>>(cnt, cols, mid, out.as<unsigned long long>());
-    SPAM_CHECK_LAUNCH();
-    SPAM_HIP_TRY(hipMemcpyAsync(h, out.p, 16, hipMemcpyDeviceToHost, s));
-    SPAM_HIP_TRY(hipStreamSynchronize(s));
-    if (h[0] <= kmax) {
-      hi = mid;
-      best[0] = h[0], best[1] = h[1];
-    } else {
-      lo = mid + 1;
-    }
-  }
-  *t_out = lo;
-  *n_out = best[0];
-  *mass_out = best[1];
-  return SPAM_OK;
 }
 
 // =====================================================================================================
@@ -1289,8 +1287,10 @@ static int sliced_dispatch(const SlicedPlan* q, const T* x, hipStream_t s, unsig
 
 // Build the sliced structure.  Returns SPAM_OK with *out = nullptr when the matrix does not qualify.
 template <class T>
-static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hipStream_t s, SlicedPlan** out) {
+static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hipStream_t s, SlicedPlan** out,
+                          const ColStats* shared = nullptr) {
   *out = nullptr;
+  PhaseClock pc(kn.prof == 4, s);
   const int slice_kb = kn.slice_kb;   // table bytes per XCD (of its 4 MB L2)
   // the hottest slots of every slab are laid out contiguously (they stay in the CU's L1) and, when they cover enough
   // of the gathers to pay for the lost occupancy, copied to LDS by every workgroup.  SPAM_SPMV_LDS_KB: -1 decide
@@ -1307,16 +1307,17 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   const unsigned gc = (unsigned)(((uint64_t)cols + 255) / 256), gr = (unsigned)(((uint64_t)rows + 255) / 256);
 
   // -- columns: histogram, level thresholds --------------------------------------------------------------
-  DevBuf cnt;
-  SPAM_TRY(cnt.alloc((uint64_t)cols * 4));
-  SPAM_HIP_TRY(hipMemsetAsync(cnt.p, 0, (uint64_t)cols * 4, s));
-  col_count_kernel<<<8192, 256, 0, s>>>(a->col_idx, a->nnz, cnt.as<uint32_t>());
-  SPAM_CHECK_LAUNCH();
+  ColStats own;
+  if (!shared) {
+    SPAM_TRY(col_stats(a, &own, s));
+    shared = &own;
+  }
+  const DevBuf& cnt = shared->cnt;
   uint32_t t_tab = 1, t_lds = 0x7FFFFFFFu, t_single = 1;
   uint64_t n_tab = 0, m_tab = 0, n_lds = 0, m_lds = 0, n_single = 0, m_single = 0;
-  SPAM_TRY(bisect_threshold(cnt.as<uint32_t>(), cols, NSLAB * smax, s, &t_tab, &n_tab, &m_tab));
-  SPAM_TRY(bisect_threshold(cnt.as<uint32_t>(), cols, smax, s, &t_single, &n_single, &m_single));
-  if (lmax) SPAM_TRY(bisect_threshold(cnt.as<uint32_t>(), cols, NSLAB * lmax, s, &t_lds, &n_lds, &m_lds));
+  SPAM_TRY(threshold_from_sorted(shared, NSLAB * smax, s, &t_tab, &n_tab, &m_tab));
+  SPAM_TRY(threshold_from_sorted(shared, smax, s, &t_single, &n_single, &m_single));
+  if (lmax) SPAM_TRY(threshold_from_sorted(shared, NSLAB * lmax, s, &t_lds, &n_lds, &m_lds));
   if (n_lds == 0) t_lds = 0x7FFFFFFFu;
   const double cover_tab = (double)m_tab / (double)a->nnz, cover_single = (double)m_single / (double)a->nnz;
   if (!force && cover_tab - cover_single < 0.10) return SPAM_OK;  // eight tables would hold little more than one
@@ -1327,6 +1328,7 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   S1 = std::max<uint32_t>(line_slots, (S1 + line_slots - 1) / line_slots * line_slots);
   const uint32_t S = L + S1;
 
+  pc.stamp("  sliced: thresholds");
   SlicedPlan* q = new (std::nothrow) SlicedPlan();
   if (!q) return set_error(SPAM_E_OOM, "host allocation failed");
   struct Guard {
@@ -1420,9 +1422,11 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
     res->col_idx = (uint32_t*)rc.release();
     res->vals = rv.release();
   }
+  pc.stamp("  sliced: column maps, row lists, residual");
   // -- the long rows: row-group form (spam_spmv_rg.hip) or slab CSRs ------------------------------------------
   if (kn.rg)
     SPAM_TRY(rg_build<T>(a, slab.as<uint8_t>(), code.as<uint32_t>(), long_rows.as<uint32_t>(), nl, S, res, q->ns, kn.rgk, s, &q->rg));
+  pc.stamp("  sliced: row-group plan (rg_build)");
   DevBuf cnt8, sc64, srow, sbase_d;
   DevBuf scol, sval, sfo, scarry, partial, xh, descs, heads;
   if (!q->rg) SPAM_TRY(partial.alloc((uint64_t)NPART * nl * sizeof(T)));  // (the row-group form keeps its pair sums)
@@ -1717,12 +1721,20 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
     ~Guard() { if (p) spmv_plan_free(p); }
   } guard{p};
   p->knobs = read_knobs();
+  PhaseClock pc(p->knobs.prof == 4, s);
   SPAM_TRY(build_tile_map<OffT>(a, row_ptr, p, sizeof(T), s));
-  SPAM_TRY(spmv_hot_analyse<T>(a, p, p->knobs.hot_kb, s));
+  pc.stamp("row -> tile map");
+  ColStats cs;
+  const bool want_stats = a->cols < 0xFFFFFFFFull && (p->knobs.hot_kb > 0 || p->knobs.sliced);
+  if (want_stats) SPAM_TRY(col_stats(a, &cs, s));
+  pc.stamp("column histogram + sort");
+  SPAM_TRY(spmv_hot_analyse<T>(a, p, p->knobs.hot_kb, s, want_stats ? &cs : nullptr));
+  pc.stamp("plain path: hot-column table");
   const int sl_cfg = p->knobs.sliced;
   if (sl_cfg) {
     SlicedPlan* q = nullptr;
-    SPAM_TRY(sliced_analyse<T>(a, p->knobs, sl_cfg == 2, s, &q));
+    SPAM_TRY(sliced_analyse<T>(a, p->knobs, sl_cfg == 2, s, &q, want_stats ? &cs : nullptr));
+    pc.stamp("sliced analysis (all of it)");
     if (q && sl_cfg == 1) {  // keep it only if it is faster on this matrix
       struct QGuard {
         SlicedPlan* q;
@@ -1750,6 +1762,7 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
         q = nullptr;  // (freed by the guard)
       }
     }
+    pc.stamp("timed comparison plain / sliced");
     p->sliced = q;
     if (q) {  // the plain path's hot-column table (4 bytes per entry) is not read again on this handle
       SPAM_HIP_TRY(hipStreamSynchronize(s));

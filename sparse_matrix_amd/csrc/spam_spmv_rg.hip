@@ -523,6 +523,17 @@ struct RgGroup {
 
 }  // namespace
 
+int sort_u32_desc(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t s) {
+  if (n == 0) return SPAM_OK;
+  size_t tb = 0;
+  SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, tb, d_in, d_out, (int64_t)n, 0, 32, s));
+  DevBuf tmp;
+  SPAM_TRY(tmp.alloc(tb));
+  SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(tmp.p, tb, d_in, d_out, (int64_t)n, 0, 32, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));  // tmp goes back to the pool
+  return SPAM_OK;
+}
+
 void rg_plan_free(RgPlan* g) {
   if (!g) return;
   void* ptrs[] = {g->stream, g->blk, g->pe, g->sub_head, g->slot_rows, g->mask_slot, g->tiles, g->grp_cp, g->cp, g->vsrc};
@@ -546,6 +557,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   const uint64_t ecap = eblk * SPMV_NPART;  // entries of a group over its nine blocks
   const uint64_t max_sub = std::min<uint64_t>(RG_MAX_SUB, rmax / 2);
 
+  PhaseClock pc(kn.prof == 4, s);
   // -- sliced rows: length, part mask; ranks by length ----------------------------------------------------------------
   DevBuf len, key_in, key_out, idx_in, idx_out, mask, tmp;
   SPAM_TRY(len.alloc((uint64_t)nl * 4));
@@ -582,6 +594,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_HIP_TRY(hipMemcpyAsync(&n_ent, lofs.as<uint64_t>() + nl, 8, hipMemcpyDeviceToHost, s));
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (n_ent == 0 || n_ent >= 0xFFFFFFFFull) return SPAM_OK;
+  pc.stamp("    rg: row lengths, masks, rank sort, downloads");
 
   // -- row groups and tiles (host): consecutive ranks; per part at most rmax accumulators, ecap entries in all.  Ranks
   //    are placed in SLOTS: a group starts on a multiple of 64 slots, so that tile t is slots [64 t, 64 t + 64) ----------
@@ -603,12 +616,20 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
       h_mask_s.resize((size_t)h_tiles.size() * 64, (uint16_t)0);
     };
     open_tile();
-    for (uint32_t k = 0; k < nl; ++k) {
+    // The leading ranks whose rows take extra accumulators (nsub > 1: a few thousand rows at most) are placed one by one
+    // and may close a group anywhere; everything behind them is placed a whole tile at a time and closes groups on tile
+    // boundaries only (64 masks -> nine counts), which keeps this loop at a few milliseconds for millions of rows.
+    auto nsub_of = [&](uint64_t L) {
+      uint64_t n = (L * RG_MAX_SUB + ecap - 1) / ecap;
+      return std::min<uint64_t>(std::max<uint64_t>(n, 1), std::min<uint64_t>(max_sub, std::max<uint64_t>(L, 1)));
+    };
+    uint32_t khub = 0;  // ranks [0, khub) are placed one by one (lengths are non-increasing there)
+    while (khub < nl && nsub_of(h_len[khub]) > 1) ++khub;
+    for (uint32_t k = 0; k < khub; ++k) {
       const uint64_t L = h_len[k];
       // a row holding the fraction f of a block's entries draws 64 f lanes of every wave instruction: 8 x as many
       // accumulators keep two lanes off one LDS address most of the time
-      uint64_t nsub = (L * RG_MAX_SUB + ecap - 1) / ecap;
-      nsub = std::min<uint64_t>(std::max<uint64_t>(nsub, 1), std::min<uint64_t>(max_sub, std::max<uint64_t>(L, 1)));
+      const uint64_t nsub = nsub_of(L);
       if (nsub > 1) h_mask[k] = (uint16_t)RG_FULL_MASK;  // its extra accumulators exist in every part: so do its heads
       const uint32_t m = h_mask[k];
       uint32_t worst = 0;
@@ -618,11 +639,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
         cur = RgGroup{};
         ents = 0;
         slot = (slot + 63u) & ~63u;
-        if (slot == (uint32_t)h_tiles.size() * 64u) open_tile();
-        else {  // (the group before ended exactly on a tile boundary and no tile was opened for this slot yet)
-          h_tiles.back().grp = (uint32_t)groups.size();
-          for (int p = 0; p < SPMV_NPART; ++p) h_tiles.back().base[p] = 0;
-        }
+        open_tile();
         cur.first_slot = slot;
       } else if (slot == (uint32_t)h_tiles.size() * 64u) {
         open_tile();
@@ -636,8 +653,50 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
       ents += L;
       ++slot;
     }
+    if (khub < nl) {
+      // the rest, tile by tile, from the next tile boundary on
+      if (khub > 0) slot = (slot + 63u) & ~63u;
+      const uint64_t rest_tiles = ((uint64_t)(nl - khub) + 63) / 64;
+      const size_t need = (size_t)slot + (size_t)rest_tiles * 64;
+      h_grp_s.resize(need, 0u), h_rsub_s.resize(need, 0u), h_mask_s.resize(need, (uint16_t)0);
+      h_tiles.reserve(need / 64);
+      if (slot < (uint32_t)h_tiles.size() * 64u) h_tiles.pop_back();  // (the tile opened before the loop, still without rows)
+      for (uint32_t k0 = khub; k0 < nl; k0 += 64, slot += 64) {
+        const uint32_t n = std::min<uint32_t>(64, nl - k0);
+        uint32_t cnt[SPMV_NPART] = {0};
+        uint64_t tents = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+          const uint32_t m = h_mask[k0 + j];
+          for (int p = 0; p < SPMV_NPART; ++p) cnt[p] += (m >> p) & 1u;
+          tents += h_len[k0 + j];
+        }
+        uint32_t worst = 0;
+        for (int p = 0; p < SPMV_NPART; ++p) worst = std::max(worst, cur.heads[p] + cnt[p]);
+        const bool group_has_rows = ents > 0;
+        if (group_has_rows && (worst + cur.nsubs > rmax || ents + tents > ecap)) {
+          groups.push_back(cur);
+          cur = RgGroup{};
+          ents = 0;
+          cur.first_slot = slot;
+        }
+        RgTile t{};
+        t.grp = (uint32_t)groups.size();
+        for (int p = 0; p < SPMV_NPART; ++p) t.base[p] = (uint16_t)cur.heads[p];
+        h_tiles.push_back(t);
+        const uint32_t gid = (uint32_t)groups.size();
+        for (uint32_t j = 0; j < n; ++j) {
+          h_slot[k0 + j] = slot + j;
+          h_grp_s[slot + j] = gid;
+          h_rsub_s[slot + j] = 1u << 16;
+          h_mask_s[slot + j] = h_mask[k0 + j];
+        }
+        for (int p = 0; p < SPMV_NPART; ++p) cur.heads[p] += cnt[p];
+        ents += tents;
+      }
+    }
     groups.push_back(cur);
   }
+  pc.stamp("    rg: groups and tiles on the host");
   const uint32_t ng = (uint32_t)groups.size();
   const uint32_t ntiles = (uint32_t)h_tiles.size();
   const uint64_t nslots = (uint64_t)ntiles * 64;
@@ -720,6 +779,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   rg_hidx_kernel<<<(ntiles + 3) / 4, 256, 0, s>>>(tiles.as<RgTile>(), ntiles, mask_slot.as<uint16_t>(), hidx.as<uint16_t>());
   SPAM_CHECK_LAUNCH();
 
+  pc.stamp("    rg: descriptors, uploads, slot kernels");
   // -- entries: key, sort by (block, slot) -------------------------------------------------------------------------------
   DevBuf keys_in, keys_out, src_in, src_out;
   const uint64_t n_all = n_ent + n_short;
@@ -746,6 +806,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_HIP_TRY(hipStreamSynchronize(s));  // the host vectors above are read by the copies
   keys_in.reset(), src_in.reset(), tmp.reset(), hidx.reset();
 
+  pc.stamp("    rg: entry keys + radix sort (incl. allocations)");
   // -- block bounds, chunk offsets ---------------------------------------------------------------------------------------
   DevBuf start;
   SPAM_TRY(start.alloc(((uint64_t)nb + 1) * 8));
@@ -790,6 +851,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
       vsrc.as<uint32_t>(), g->padded);
   SPAM_CHECK_LAUNCH();
   SPAM_HIP_TRY(hipStreamSynchronize(s));  // host vectors and temporaries go out of scope
+  pc.stamp("    rg: bounds, offsets, stream fill (incl. allocations)");
   g->stream = stream.as<unsigned char>(), stream.release();
   g->blk = blk.release();
   g->pe = pe.as<uint64_t>(), pe.release();
