@@ -1725,7 +1725,8 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
   SPAM_TRY(build_tile_map<OffT>(a, row_ptr, p, sizeof(T), s));
   pc.stamp("row -> tile map");
   ColStats cs;
-  const bool want_stats = a->cols < 0xFFFFFFFFull && (p->knobs.hot_kb > 0 || p->knobs.sliced);
+  // (both analyses give up on 2^31 columns and more, and neither needs the counts of a matrix without entries)
+  const bool want_stats = a->cols < 0x7FFFFFFFull && a->nnz > 0 && (p->knobs.hot_kb > 0 || p->knobs.sliced);
   if (want_stats) SPAM_TRY(col_stats(a, &cs, s));
   pc.stamp("column histogram + sort");
   SPAM_TRY(spmv_hot_analyse<T>(a, p, p->knobs.hot_kb, s, want_stats ? &cs : nullptr));
