@@ -1346,9 +1346,12 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
     const double miss = std::max(0.05, 1.0 - cover_single);
     int lm = (int)std::ceil(1.8 / miss);
     lm = std::min(64, std::max(2, lm));
-    // the row-group form keeps one accumulator per (row, part) pair that exists, so even one-entry rows are cheaper
-    // sliced (12 B entry + 16 B pair) than gathered from x past the tables (a 128-byte line per miss)
-    q->long_min = (uint32_t)(kn.long_min > 0 ? kn.long_min : (kn.rg ? 1 : lm));
+    // the row-group form keeps one accumulator per (row, part) pair that exists, so short rows are cheaper sliced
+    // (12 B entry + 16 B pair sum + their share of the reduce) than gathered from x past the tables (a 128-byte line
+    // per miss) — down to rows of 3 entries; rows of one or two run as unsliced blocks of the same kernel (measured on
+    // the R-MAT bench matrix: thresholds 1 / 2 / 3 / 4 / 5 / 7 / 9 / 13 / 17 -> 0.578 / 0.579 / 0.567 / 0.567 / 0.568 / 0.569 /
+    // 0.569 / 0.576 / 0.603 ms; reading those rows' table columns from the slab tables instead of x: no difference)
+    q->long_min = (uint32_t)(kn.long_min > 0 ? kn.long_min : (kn.rg ? 3 : lm));
   }
 
   DevBuf f0, f1, p0, p1, tmp, code, slab, dest;

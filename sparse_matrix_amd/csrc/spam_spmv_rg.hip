@@ -18,7 +18,7 @@
 //     order and writes y[row].
 // Rows that would draw most lanes of a wave instruction to one LDS address get extra accumulators behind the block's
 // heads (an entry picks one by its position in the row); they are folded into their head before the sums are stored.
-// Rows below the sliced-row threshold (none by default) join as a tenth kind of block: consecutive short rows, all
+// Rows below the sliced-row threshold (by default: rows of one or two entries) join as a tenth kind of block: consecutive short rows, all
 // their entries unsliced in column order, gathered from x itself, results written straight to y.
 //
 // The kernel runs at the fabric's byte rate: what a change saves is the bytes it no longer moves.

@@ -197,7 +197,8 @@ def test_row_block_view_forced(spam, oracle, sliced_env):
 @pytest.mark.parametrize("cfg", [dict(RG_EBLK=1024), dict(RG_EBLK=1024, RG_ABITS=9), dict(RG_ABITS=10, RG_NT=1024, RG_K=2),
                                  dict(RG_EBLK=4096, RG_NT=256), dict(RG_EBLK=2048, RG_NT=1024, RG_K=4, LONG=1),
                                  dict(RG_EBLK=1024, RG_SHORT=0, LONG=9), dict(RG_ABITS=9, LONG=40), dict(RG_EBLK=1024, LONG=7),
-                                 dict(RG_ORDER=1000, RG_EBLK=4096), dict(RG_ORDER=1), dict(RG_ORDER=4, LONG=3, RG_EBLK=1024)])
+                                 dict(RG_ORDER=1000, RG_EBLK=4096), dict(RG_ORDER=1), dict(RG_ORDER=4, LONG=3, RG_EBLK=1024),
+                                 dict(LONG=1), dict(LONG=5, RG_EBLK=2048)])
 @pytest.mark.parametrize("kind", ["rmat14", "powerlaw"])
 def test_row_groups_geometries(spam, oracle, sliced_env, cfg, kind):
     """Small blocks (many groups, rows with several accumulators each), narrow accumulator fields (511 / 1023 pairs per
