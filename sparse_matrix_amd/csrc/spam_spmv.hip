@@ -1064,6 +1064,37 @@ __global__ void sliced_build_tables_kernel(const T* __restrict__ x, const uint32
   if (d != NO_DEST) xh[d] = x[i];
 }
 
+// The same with 16-byte accesses of x and y (V = 16 / sizeof(T) columns / rows per thread); x and y must be 16-byte aligned.
+template <class T, int V>
+__global__ void sliced_build_tables_vec_kernel(const T* __restrict__ x, const uint32_t* __restrict__ dest, uint32_t cols,
+                                               T* __restrict__ xh, uint32_t* __restrict__ heads, T* __restrict__ y,
+                                               uint32_t rows) {
+  typedef T TV __attribute__((ext_vector_type(V)));
+  typedef uint32_t UV __attribute__((ext_vector_type(V)));
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i = j * V;
+  if (j <= NPART) heads[j * HEAD_STRIDE] = 0;
+  if (i + V <= rows) {
+    TV z;
+#pragma unroll
+    for (int v = 0; v < V; ++v) z[v] = T(0);
+    *reinterpret_cast<TV*>(y + i) = z;
+  } else {
+    for (uint64_t r = i; r < rows; ++r) y[r] = T(0);
+  }
+  if (i + V <= cols) {
+    const UV d = *reinterpret_cast<const UV*>(dest + i);
+    const TV xv = *reinterpret_cast<const TV*>(x + i);
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+      if (d[v] != NO_DEST) xh[d[v]] = xv[v];
+  } else {
+    for (uint64_t c = i; c < cols; ++c) {
+      const uint32_t d = dest[c];
+      if (d != NO_DEST) xh[d] = x[c];
+    }
+  }
+}
+
 // ---- analysis kernels ---------------------------------------------------------------------------------
 __global__ void sliced_level_flags_kernel(const uint32_t* __restrict__ cnt, uint32_t cols, uint32_t t_lds, uint32_t t_tab,
                                           uint32_t* __restrict__ f0, uint32_t* __restrict__ f1) {
@@ -1568,7 +1599,14 @@ template <class T>
 static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, hipStream_t s) {
   const uint32_t cols = (uint32_t)a->cols;
   const uint32_t rows = (uint32_t)a->rows;
-  sliced_build_tables_kernel<T><<<(unsigned)(((uint64_t)std::max(cols, rows) + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
+  constexpr int V = 16 / (int)sizeof(T);
+  if ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0) {
+    const uint64_t nthr = ((uint64_t)std::max(cols, rows) + V - 1) / V;
+    sliced_build_tables_vec_kernel<T, V><<<(unsigned)((std::max<uint64_t>(nthr, NPART + 1) + 255) / 256), 256, 0, s>>>(
+        x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
+  } else {
+    sliced_build_tables_kernel<T><<<(unsigned)(((uint64_t)std::max(cols, rows) + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
+  }
   SPAM_CHECK_LAUNCH();
   // (running the short rows beside the slab kernel on a second stream was measured 3 % slower than one after the other)
   if (!(q->rg && q->rg->ngs)) SPAM_TRY(residual_run<T>(a, q, x, y, s));

@@ -54,7 +54,7 @@ except OSError:
 # ---- SpMV step ------------------------------------------------------------------------------------
 sp = pmc("spmv_pmc_")
 mode = bench.get("config", {}).get("spmv_plan", {}).get("mode", "?")
-step_kernels = (["sliced_build_tables_kernel", "xh_build_kernel", "spmv_short_rows_kernel", "spmv_rg_kernel", "spmv_rg_reduce_kernel"]
+step_kernels = (["sliced_build_tables_kernel", "sliced_build_tables_vec_kernel", "spmv_short_rows_kernel", "spmv_rg_kernel", "spmv_rg_reduce_kernel"]
                 if mode == "xcd_sliced_row_groups" else
                 ["sliced_build_tables_kernel", "xh_build_kernel", "spmv_short_rows_kernel", "spmv_sliced_pipe_kernel",
                  "sliced_fixup_kernel", "sliced_reduce_kernel"] if mode == "xcd_sliced" else
