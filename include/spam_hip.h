@@ -18,7 +18,8 @@
  * Unlike the reference, A.cols == B.rows is checked up front.
  *
  * Threading: a handle may be used by several host threads at once for SpMV / SpGEMM / downloads (the lazily
- * built SpMV tile map is created under a per-handle lock); spam_spmv_prepare, spam_csr_values_changed,
+ * built SpMV tile map is created under a per-handle lock, and the launches of one SpMV — which share the plan's
+ * scratch buffers — are enqueued as a unit under a second one); spam_spmv_prepare, spam_csr_values_changed,
  * spam_csr_sort_rows and spam_csr_free need exclusive use of the handle.  The stream selection is process-global and
  * the device allocator recycles blocks without stream ordering: use ONE stream per process (spam_hip_set_stream once,
  * before any other call).  One process drives one GPU (one rank per GPU under RCCL).

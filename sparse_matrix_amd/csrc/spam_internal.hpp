@@ -112,6 +112,8 @@ struct spam_csr {
   bool owns_row_ptr = false, owns_row_ptr32 = false, owns_col_val = false;
   spam::SpmvPlan* spmv_plan = nullptr;  // built by spam_spmv_prepare or on the first SpMV; read-only afterwards
   std::mutex plan_mu;                   // serialises its construction (handles may be used from several host threads)
+  std::mutex run_mu;  // serialises the ENQUEUE of one SpMV's kernels: they share the plan's scratch (tables, queue heads, pair
+                      // sums, carries), which is safe in stream order but not when two threads' launches interleave
 };
 
 namespace spam {

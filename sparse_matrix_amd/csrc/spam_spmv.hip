@@ -1735,6 +1735,8 @@ static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, 
   }
   if (!__atomic_load_n(&a->spmv_plan, __ATOMIC_ACQUIRE)) SPAM_TRY((ensure_plan<T, OffT>(a, row_ptr, s)));
   const SpmvPlan* pm = a->spmv_plan;
+  // one SpMV = several launches over the plan's scratch buffers: enqueue them as one unit (all calls share ONE stream)
+  std::lock_guard<std::mutex> run(const_cast<spam_csr*>(a)->run_mu);
   if (pm->sliced) return sliced_run<T>(a, pm->sliced, x, y, s);
   return plain_run<T, OffT>(a, row_ptr, x, y, s);
 }

@@ -249,3 +249,53 @@ def test_row_groups_i64_exact_and_values_changed(spam, oracle, sliced_env):
     B.spmv_dev(tx.data_ptr(), ty.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(ty.cpu().numpy(), oracle.spmv((off, idx, val * 3), x))
+
+
+@pytest.mark.parametrize("prepared", [True, False], ids=["prepared", "plain"])
+def test_one_handle_from_several_host_threads(spam, oracle, sliced_env, prepared):
+    """spam_hip.h: a handle may serve SpMVs from several host threads at once.  One SpMV is several launches over the
+    plan's scratch (tables, queue heads, pair sums, carries): the library enqueues them as a unit.  Four threads, each
+    with its own x and y on one handle (ctypes releases the GIL during the calls); i64, so any mix-up of two threads'
+    tables or sums shows as a wrong integer."""
+    import threading
+    sliced_env(SLICE_KB=8, RG_EBLK=1024)
+    m = synth.rmat(12)
+    off, idx, _ = csr_np(m)
+    rng = np.random.default_rng(17)
+    val = rng.integers(-2**40, 2**40, idx.size, dtype=np.int64)
+    dev = torch.device("cuda", 0)
+    B = spam.DeviceCsr.from_torch(m.rows, m.cols, torch.from_numpy(off.astype(np.int64)).to(dev),
+                                  torch.from_numpy(idx.astype(np.int32)).to(dev), torch.from_numpy(val).to(dev), True)
+    nthreads, reps = 4, 25
+    xs = [rng.integers(-2**20, 2**20, m.cols, dtype=np.int64) for _ in range(nthreads)]
+    refs = [oracle.spmv((off, idx, val), x) for x in xs]
+    txs = [torch.from_numpy(x).to(dev) for x in xs]
+    tys = [torch.zeros(reps, m.rows, dtype=torch.int64, device=dev) for _ in range(nthreads)]
+    if prepared:
+        B.spmv_prepare(txs[0].data_ptr())
+        assert B.spmv_plan_info()["sliced"]["active"]
+    else:
+        B.spmv_dev(txs[0].data_ptr(), tys[0][0].data_ptr())  # (the lazily built plain plan)
+    torch.cuda.synchronize()
+    errors = []
+    start = threading.Barrier(nthreads)
+
+    def work(t):
+        try:
+            start.wait()
+            for r in range(reps):
+                B.spmv_dev(txs[t].data_ptr(), tys[t][r].data_ptr())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for t in range(nthreads):
+        got = tys[t].cpu().numpy()
+        for r in range(reps):
+            assert np.array_equal(got[r], refs[t]), f"thread {t} repeat {r}"
