@@ -24,4 +24,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES 
   echo "spgemm pmc $grp done" >> $OUT/progress.txt
 done
 python3 tools/pmc_summary.py $OUT
-cat $OUT/errors.log 2>/dev/null
+if [ -s $OUT/errors.log ]; then cat $OUT/errors.log; exit 1; fi
+exit 0
