@@ -5,6 +5,10 @@ Same names, argument meaning and error behaviour as the Rust type (spam_csr/src/
 ``mul_hash`` (spam_csr/src/mul_hash.rs:13-36) and the new ``spmv`` run on the GPU through the C ABI in
 include/spam_hip.h.  ``+`` / ``-`` (apply_elementwise, lib.rs:83-149) also run on the device; element get/set and transpose stay with the
 reference's CPU code and are not provided here.
+
+Element types: f32, f64 and i64 (= Wrapping<i64>) are device types.  i8 / i16 / i32 (Wrapping<i8> is what the reference's
+own mul_hash test uses, tests.rs:358) run as i64 and are truncated back, which is exact; complex64 / complex128 run as
+four real products (two real sums for ``+`` / ``-``) over one sparsity pattern.
 """
 from __future__ import annotations
 
@@ -18,6 +22,14 @@ from ._lib import DTYPE_SUFFIX, SPAM_F32, SPAM_F64, SPAM_I64, SpamError, SpgemmS
 # int64 = Wrapping<i64> (the reference's integer type: tests.rs:356-371 uses Wrapping<i8>, the bench parses i64)
 _NP2DT = {np.dtype(np.float32): SPAM_F32, np.dtype(np.float64): SPAM_F64, np.dtype(np.int64): SPAM_I64}
 _DT2NP = {SPAM_F32: np.float32, SPAM_F64: np.float64, SPAM_I64: np.int64}
+# The other element types the reference instantiates CsrMatrix with reach the three device types from the host side:
+#   * Wrapping<i8> (tests.rs:358), i16, i32: Z/2^64 -> Z/2^k is a ring homomorphism, so the values are widened to i64,
+#     multiplied and added with 64-bit wrapping on the device and truncated back — bit-exact, not an approximation;
+#   * Complex<f32/f64> (the fuzz targets and MatrixType::Complex, lib.rs:428-430): products and sums are bilinear, so
+#     C = (Ar Br - Ai Bi) + i (Ar Bi + Ai Br) from four real products that share one sparsity pattern (mul_hash's
+#     pattern depends on the indices only and keeps computed zeros).  Same result as complex arithmetic up to rounding.
+_WIDEN = {np.dtype(np.int8): np.int64, np.dtype(np.int16): np.int64, np.dtype(np.int32): np.int64}
+_COMPLEX_PART = {np.dtype(np.complex64): np.float32, np.dtype(np.complex128): np.float64}
 
 
 def _typed(name: str, dt: int):
@@ -45,7 +57,7 @@ class DeviceCsr:
         indices = np.ascontiguousarray(indices, dtype=np.uint64)
         vals = np.ascontiguousarray(vals)
         if vals.dtype not in _NP2DT:
-            raise TypeError(f"GPU path supports f32 / f64 / int64 values, not {vals.dtype}")
+            raise TypeError(f"device handles hold f32 / f64 / int64 values, not {vals.dtype} (CsrMatrix widens i8/i16/i32 and splits complex)")
         if offsets.size != rows + 1:
             raise SpamError(1, "len(offsets) != rows + 1 (invariant 2)")
         if indices.size != vals.size:
@@ -249,6 +261,7 @@ class CsrMatrix:
         self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.is_sorted = bool(is_sorted)
         self._dev = None
+        self._parts = None  # complex values: the (real, imaginary) CsrMatrix pair, built on first use
 
     # -- Matrix trait (spam_matrix/src/lib.rs:15-27) ----------------------------------------
     @classmethod
@@ -328,9 +341,34 @@ class CsrMatrix:
 
     # -- device ------------------------------------------------------------------------------
     def device(self) -> DeviceCsr:
+        """The uploaded copy.  Narrow integers are uploaded as i64; a complex matrix answers with the handle of its
+        real part (same structure: enough for invariants() and the dimension queries)."""
+        if self.vals.dtype in _COMPLEX_PART:
+            return self._real_imag()[0].device()
         if self._dev is None:
-            self._dev = DeviceCsr.upload(self._rows, self._cols, self.offsets, self.indices, self.vals, self.is_sorted)
+            vals = self.vals.astype(_WIDEN[self.vals.dtype]) if self.vals.dtype in _WIDEN else self.vals
+            self._dev = DeviceCsr.upload(self._rows, self._cols, self.offsets, self.indices, vals, self.is_sorted)
         return self._dev
+
+    def _device_dtype(self):
+        return np.dtype(_WIDEN.get(self.vals.dtype, self.vals.dtype))
+
+    def _narrow(self, vals):
+        """Device values back in this matrix's element type (i64 -> i8/i16/i32 keeps the low bits: Wrapping<T>)."""
+        return vals.astype(self.vals.dtype) if self.vals.dtype in _WIDEN else vals
+
+    def _real_imag(self):
+        if self._parts is None:
+            part = _COMPLEX_PART[self.vals.dtype]
+            self._parts = tuple(CsrMatrix(self._rows, self._cols, np.ascontiguousarray(v, dtype=part), self.indices,
+                                          self.offsets, self.is_sorted) for v in (self.vals.real, self.vals.imag))
+        return self._parts
+
+    @staticmethod
+    def _same_pattern(*ms):
+        o, i = ms[0].offsets, ms[0].indices
+        if not all(np.array_equal(m.offsets, o) and np.array_equal(m.indices, i) for m in ms[1:]):
+            raise RuntimeError("the real products of a complex operation came back with different patterns")
 
     # -- the hot path ------------------------------------------------------------------------
     def mul_hash(self, rhs: "CsrMatrix", sort_output: bool = False, reference_order: bool = False) -> "CsrMatrix":
@@ -340,6 +378,20 @@ class CsrMatrix:
 
         Two phases exactly like the reference: symbolic gives nnz, the caller-side Vecs are allocated to
         that capacity (mul_hash.rs:119), numeric fills them."""
+        if self.vals.dtype != rhs.vals.dtype:
+            raise TypeError(f"both operands hold the same T (mul_hash.rs:13): {self.vals.dtype} vs {rhs.vals.dtype}")
+        if self.vals.dtype in _COMPLEX_PART:
+            if reference_order:
+                raise NotImplementedError("reference slot order is not offered for complex values")
+            # four real products, every one with sorted rows so that the four value arrays line up entry by entry
+            # (a sorted row is one of the orders B2 = false allows)
+            (ar, ai), (br, bi) = self._real_imag(), rhs._real_imag()
+            rr, ii, ri, ir = (x.mul_hash(y, sort_output=True) for x, y in ((ar, br), (ai, bi), (ar, bi), (ai, br)))
+            self._same_pattern(rr, ii, ri, ir)
+            vals = np.empty(rr.vals.size, dtype=self.vals.dtype)
+            vals.real = rr.vals - ii.vals
+            vals.imag = ri.vals + ir.vals
+            return CsrMatrix(self._rows, rhs._cols, vals, rr.indices, rr.offsets, is_sorted=sort_output)
         L = _lib.load()
         a, b = self.device(), rhs.device()
         plan = C.c_void_p()
@@ -348,18 +400,27 @@ class CsrMatrix:
         try:
             offsets = np.empty(self._rows + 1, dtype=np.uint64)
             indices = np.empty(nnz.value, dtype=np.uint64)
-            vals = np.empty(nnz.value, dtype=self.vals.dtype)
-            fn = _typed("spgemm_numeric", _NP2DT[self.vals.dtype])
+            vals = np.empty(nnz.value, dtype=self._device_dtype())
+            fn = _typed("spgemm_numeric", _NP2DT[self._device_dtype()])
             order = 1 if sort_output else (2 if reference_order else 0)
             check(fn(plan, order, _vp(offsets), _vp(indices), _vp(vals)))
         finally:
             L.spam_spgemm_plan_free(plan)
-        return CsrMatrix(self._rows, rhs._cols, vals, indices, offsets, is_sorted=sort_output)
+        return CsrMatrix(self._rows, rhs._cols, self._narrow(vals), indices, offsets, is_sorted=sort_output)
 
     def _ewise(self, rhs: "CsrMatrix", subtract: bool) -> "CsrMatrix":
+        if self.vals.dtype != rhs.vals.dtype:
+            raise TypeError(f"both operands hold the same T: {self.vals.dtype} vs {rhs.vals.dtype}")
+        if self.vals.dtype in _COMPLEX_PART:  # (a + ib) +- (c + id), part by part; zeros are kept, so one pattern
+            (ar, ai), (br, bi) = self._real_imag(), rhs._real_imag()
+            re, im = ar._ewise(br, subtract), ai._ewise(bi, subtract)
+            self._same_pattern(re, im)
+            vals = np.empty(re.vals.size, dtype=self.vals.dtype)
+            vals.real, vals.imag = re.vals, im.vals
+            return CsrMatrix(self._rows, self._cols, vals, re.indices, re.offsets, is_sorted=True)
         d = self.device().add(rhs.device(), subtract)
         o, i, v = d.download()
-        return CsrMatrix(self._rows, self._cols, v, i, o, is_sorted=True)
+        return CsrMatrix(self._rows, self._cols, self._narrow(v), i, o, is_sorted=True)
 
     def __add__(self, rhs):
         """``impl Add for CsrMatrix`` (spam_csr/src/lib.rs:276-282)."""
@@ -378,7 +439,18 @@ class CsrMatrix:
     def spmv(self, x, prepare: bool = False) -> np.ndarray:
         """y = A x (absent upstream; defined as mul_hash with an n x 1 rhs).  ``prepare`` runs the
         SpMV analysis on the (cached) device copy first — worth it when the matrix is multiplied many times."""
+        x = np.asarray(x)
+        if self.vals.dtype in _COMPLEX_PART:  # y = (Ar xr - Ai xi) + i (Ar xi + Ai xr)
+            ar, ai = self._real_imag()
+            x = x.astype(self.vals.dtype)
+            xr, xi = np.ascontiguousarray(x.real), np.ascontiguousarray(x.imag)
+            y = np.empty(self._rows, dtype=self.vals.dtype)
+            y.real = ar.spmv(xr, prepare) - ai.spmv(xi, prepare)
+            y.imag = ar.spmv(xi) + ai.spmv(xr)
+            return y
         d = self.device()
         if prepare:
             d.spmv_prepare()
-        return d.spmv(np.asarray(x))
+        if self.vals.dtype in _WIDEN:
+            x = x.astype(self.vals.dtype).astype(np.int64)
+        return self._narrow(d.spmv(x))
