@@ -85,17 +85,19 @@ class Gathered:
 
 
 def allgather_csr(row_ptr: torch.Tensor, col_idx: torch.Tensor, vals: torch.Tensor, row_offsets: list[int], rank: int,
-                  world: int, dist=None, async_vals: bool = False) -> Gathered:
+                  world: int, dist=None, async_vals: bool = False, force_collectives: bool = False) -> Gathered:
     """All-gather-v of row-block-distributed CSR shards into the full matrix on every rank.
 
     row_offsets[r] .. row_offsets[r+1] = the rows rank r holds (any contiguous split); row_ptr int64[rows_local+1]
     (block-local offsets starting at 0), col_idx int32[nnz_local], vals[nnz_local].  Returns a `Gathered` whose
     row_ptr is globalised by each source's entry offset.  With async_vals the caller gets control back while vals
     is still in flight: call wait_structure(), run the symbolic phase, then wait_values().
+    force_collectives: issue the collectives in a world of one as well (a 1-GPU box can then run the RCCL calls —
+    all_reduce, grouped send/recv to self — that the 8-GPU run makes; tests/test_rccl_world1_gpu.py).
     """
     dev = col_idx.device
     n_rows = row_offsets[-1]
-    if world == 1 or dist is None:
+    if (world == 1 and not force_collectives) or dist is None:
         nb = int(col_idx.numel()) * (col_idx.element_size() + vals.element_size()) + (n_rows + 1) * 8
         return Gathered(row_ptr, col_idx, vals, [None, None, None], {"bytes_received": 0, "bytes_unpadded": nb, "mode": "local"})
     nnz_local = int(col_idx.numel())
@@ -171,10 +173,11 @@ def balanced_row_blocks(row_flops, nparts: int, row_overhead: int = ROW_OVERHEAD
     return rows_to_parts_host(f + row_overhead * (f > 0).to(torch.int64), nparts)
 
 
-def allgather_vector(x_local: torch.Tensor, n: int, rank: int, world: int, dist=None) -> torch.Tensor:
+def allgather_vector(x_local: torch.Tensor, n: int, rank: int, world: int, dist=None,
+                     force_collectives: bool = False) -> torch.Tensor:
     """Row-sharded SpMV needs all of x: every rank owns x[equal_row_block] and receives the rest (one padded
     all-gather; 8 B * n / world per peer link; equal blocks differ by at most one element)."""
-    if world == 1 or dist is None:
+    if (world == 1 and not force_collectives) or dist is None:
         return x_local
     blocks = [equal_row_block(n, r, world) for r in range(world)]
     maxb = max(hi - lo for lo, hi in blocks)
