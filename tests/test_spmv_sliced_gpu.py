@@ -299,3 +299,46 @@ def test_one_handle_from_several_host_threads(spam, oracle, sliced_env, prepared
         got = tys[t].cpu().numpy()
         for r in range(reps):
             assert np.array_equal(got[r], refs[t]), f"thread {t} repeat {r}"
+
+
+@pytest.mark.parametrize("prepared", [True, False], ids=["prepared", "plain"])
+def test_spmv_is_legal_under_stream_capture(spam, oracle, sliced_env, prepared):
+    """After spam_spmv_prepare (or a first SpMV) a product is kernel launches on the library's stream and nothing else —
+    no allocation, no synchronisation, no host read-back — so it can be recorded into a HIP graph and replayed; x and y
+    are read / written in place at replay."""
+    sliced_env(SLICE_KB=8, RG_EBLK=1024)
+    from sparse_matrix_amd import _lib
+    m = synth.rmat(12)
+    off, idx, val = csr_np(m)
+    dev = torch.device("cuda", 0)
+    B = spam.DeviceCsr.from_torch(m.rows, m.cols, torch.from_numpy(off.astype(np.int64)).to(dev),
+                                  torch.from_numpy(idx.astype(np.int32)).to(dev), torch.from_numpy(val).to(dev), True)
+    rng = np.random.default_rng(23)
+    x = torch.from_numpy(rng.uniform(0.5, 1.5, m.cols)).to(dev)
+    y = torch.zeros(m.rows, dtype=torch.float64, device=dev)
+    L = _lib.load()
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            _lib.check(L.spam_hip_set_stream(side.cuda_stream))
+            if prepared:
+                B.spmv_prepare(x.data_ptr())
+                assert B.spmv_plan_info()["sliced"]["active"]
+            B.spmv_dev(x.data_ptr(), y.data_ptr())  # (plain: builds the lazily created tile map outside the capture)
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                B.spmv_dev(x.data_ptr(), y.data_ptr())
+                B.spmv_dev(x.data_ptr(), y.data_ptr())
+        torch.cuda.synchronize()
+        for rep in range(3):
+            xn = rng.uniform(0.5, 1.5, m.cols)
+            x.copy_(torch.from_numpy(xn).to(dev))
+            y.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            ref1 = oracle.spmv((off, idx, val), xn)
+            # (the graph holds the product twice: the second run overwrites y with the same result)
+            assert np.allclose(y.cpu().numpy(), ref1, rtol=1e-12, atol=0), f"replay {rep}"
+    finally:
+        _lib.check(L.spam_hip_set_stream(torch.cuda.current_stream().cuda_stream))
