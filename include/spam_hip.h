@@ -141,7 +141,10 @@ int spam_csr_add(const spam_csr* a, const spam_csr* b, int subtract, spam_csr** 
 int spam_spmv_f64(const spam_csr* a, const double* x_host, double* y_host); /* host slices (&[T] -> Vec<T>) */
 int spam_spmv_f32(const spam_csr* a, const float* x_host, float* y_host);
 int spam_spmv_i64(const spam_csr* a, const int64_t* x_host, int64_t* y_host);
-int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y); /* device-resident vectors, asynchronous */
+/* Device-resident vectors, asynchronous.  d_x and d_y must not overlap.  On a handle that was prepared, or has
+ * multiplied once, the call only enqueues kernels on the library's stream (no allocation, synchronisation or host
+ * read-back): it may be recorded into a HIP graph by stream capture and replayed (tests/test_spmv_sliced_gpu.py). */
+int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y);
 /* The analysis step (CSR-adaptive's row binning; here: row -> tile map, hot-column table, XCD-sliced structure), done
  * ONCE per matrix and never inside spam_spmv_*: reads the SPAM_SPMV_* environment knobs, synchronises with the host,
  * and — when the matrix qualifies for the XCD-sliced path — times three SpMVs of either path on d_x (NULL: a vector of
