@@ -161,10 +161,11 @@ int spam_csr_values_changed(spam_csr* a);
 /* What the SpMV analysis of this matrix decided (valid after spam_spmv_prepare): number of columns in the
  * L2-resident hot table (0 = disabled), the share of the entries they cover, and the number of nnz tiles. */
 int spam_spmv_plan_info(const spam_csr* a, uint64_t* hot_columns, double* hot_cover, uint64_t* tiles);
-/* XCD-sliced mode (valid after spam_spmv_prepare): when x is larger than one XCD's L2 and eight per-XCD x-tables cover
- * clearly more gathers than one, the analysis deals the most referenced columns over 8 slabs, stores the rows of
- * >= long_min entries as 8 slab CSRs (+ 8 partial y vectors, added in slab order) and keeps the shorter rows in a
- * residual CSR; spam_spmv_prepare times both paths and keeps the faster one.  *active = 1 when the
+/* XCD-sliced mode (valid after spam_spmv_prepare): the analysis deals the most referenced columns over 8 slabs, one
+ * x-table per XCD's L2, and stores the rows of >= long_min entries slab by slab — in row-group form (below; a candidate
+ * from 3 M entries on, whatever the size of x) or, with SPAM_SPMV_RG=0, as 8 slab CSRs + 8 partial y vectors added in
+ * slab order (a candidate when x is larger than one L2 and eight tables cover clearly more gathers than one) — and the
+ * shorter rows in a residual CSR; spam_spmv_prepare times both paths and keeps the faster one.  *active = 1 when the
  * sliced path won; the other outputs describe it (rows / entries in the slabs, table slots per XCD, slots also held
  * in LDS, share of the gathers covered by the 8 tables / by one table, the two timings in ms).  Environment:
  * SPAM_SPMV_SLICED = 0 never, 1 decide (default), 2 always. */
@@ -172,8 +173,8 @@ int spam_spmv_sliced_info(const spam_csr* a, int* active, uint64_t* long_rows, u
                           uint64_t* lds_slots, double* cover_table, double* cover_single, double* ms_plain,
                           double* ms_sliced);
 /* The long rows of a sliced plan are kept in ROW-GROUP form unless SPAM_SPMV_RG=0 (spam_spmv_rg.hip): per part and
- * group of up to 8191 rows one block whose entries are stored in table-slot order and whose y accumulators live in
- * LDS.  *active = 1 when the handle's plan has that form; row groups, non-empty (part, group) blocks, accumulators
+ * group of up to 8191 rows one block (16 k .. 200 k entries, following the size of the matrix; SPAM_SPMV_RG_EBLK) whose
+ * entries are stored in table-slot order and whose y accumulators live in LDS.  *active = 1 when the handle's plan has that form; row groups, non-empty (part, group) blocks, accumulators
  * (rows that would serialise LDS atomics get several), bytes of the entry stream one SpMV reads, bytes of HBM the
  * form holds.  In this form f32 / f64 sums are accumulated by LDS atomics: results agree with the reference to
  * rounding (1e-10 / 1e-5 bars) but are not bit-identical from run to run; i64 results are exact. */

@@ -150,7 +150,7 @@ constexpr int SPMV_HEAD_STRIDE = 64;        // u32 words between two queue heads
 
 // ---- SpMV, row-group form of the sliced path's long rows (spam_spmv_rg.hip) ------------------------------------------
 struct RgKnobs {
-  int eblk = 200000;  // SPAM_SPMV_RG_EBLK   entries of a (part, row group) block aimed at
+  int eblk = 0;       // SPAM_SPMV_RG_EBLK   entries of a (part, row group) block aimed at (0: entries / 500 within 16 k .. 200 k)
   int nt = 512;       // SPAM_SPMV_RG_NT     threads per workgroup (256 / 512 / 1024)
   int k = 4;          // SPAM_SPMV_RG_K      chunks a wavefront keeps in flight
   int acc_bits = 0;   // SPAM_SPMV_RG_ABITS  cap on the accumulator bits of an entry word (0: as many as fit, at most 13)

@@ -1333,7 +1333,15 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   if (lmax > smax) lmax = smax;
   if (!a->row_ptr32 || a->nnz == 0 || a->cols >= 0x7FFFFFFFull || a->rows >= 0xFFFFFFFFull || smax == 0) return SPAM_OK;
   if (a->cols + NSLAB * (smax + 32) >= 0xFFFFFFFFull) return SPAM_OK;
-  if (!force && (a->cols * sizeof(T) <= (4u << 20) || a->nnz < (1u << 20))) return SPAM_OK;  // x fits one L2 / too small
+  // Candidates (the timed comparison of spam_spmv_prepare has the last word).  The tile form gains from the tables only:
+  // x larger than one L2, eight tables covering clearly more gathers than one.  The row-group form also wins where x
+  // fits an L2 — its gathers are sorted by slot and served by the L1s, its sums stay in LDS — from a few million
+  // entries on (R-MAT scale 18 .. 21: 1.5 .. 2.3 x the plain path, tools/size_sweep.py); below that three launches
+  // cost what the product does.
+  if (!force && a->nnz < (1u << 20)) return SPAM_OK;
+  bool tile_form_candidate = a->cols * sizeof(T) > (4u << 20);
+  if (!force && !kn.rg && !tile_form_candidate) return SPAM_OK;
+  if (!force && kn.rg && a->nnz < (3u << 20)) return SPAM_OK;
   const uint32_t cols = (uint32_t)a->cols, rows = (uint32_t)a->rows;
   const unsigned gc = (unsigned)(((uint64_t)cols + 255) / 256), gr = (unsigned)(((uint64_t)rows + 255) / 256);
 
@@ -1351,7 +1359,8 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   if (lmax) SPAM_TRY(threshold_from_sorted(shared, NSLAB * lmax, s, &t_lds, &n_lds, &m_lds));
   if (n_lds == 0) t_lds = 0x7FFFFFFFu;
   const double cover_tab = (double)m_tab / (double)a->nnz, cover_single = (double)m_single / (double)a->nnz;
-  if (!force && cover_tab - cover_single < 0.10) return SPAM_OK;  // eight tables would hold little more than one
+  if (cover_tab - cover_single < 0.10) tile_form_candidate = false;  // eight tables would hold little more than one
+  if (!force && !kn.rg && !tile_form_candidate) return SPAM_OK;
   const uint32_t line_slots = 128 / sizeof(T);
   uint32_t L = (uint32_t)((n_lds + NSLAB - 1) / NSLAB);
   L = (L + line_slots - 1) / line_slots * line_slots;  // the level-1 part of a slab table starts on a 128-byte line
@@ -1461,6 +1470,7 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   if (kn.rg)
     SPAM_TRY(rg_build<T>(a, slab.as<uint8_t>(), code.as<uint32_t>(), long_rows.as<uint32_t>(), nl, S, res, q->ns, kn.rgk, s, &q->rg));
   pc.stamp("  sliced: row-group plan (rg_build)");
+  if (!q->rg && !force && !tile_form_candidate) return SPAM_OK;  // (row groups declined; the guard frees q)
   DevBuf cnt8, sc64, srow, sbase_d;
   DevBuf scol, sval, sfo, scarry, partial, xh, descs, heads;
   if (!q->rg) SPAM_TRY(partial.alloc((uint64_t)NPART * nl * sizeof(T)));  // (the row-group form keeps its pair sums)
@@ -1537,8 +1547,10 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   q->partial = partial.release();
   q->descs = descs.release();
   q->heads = (uint32_t*)heads.release();
-  q->code = (uint32_t*)code.release();
-  q->slab = (uint8_t*)slab.release();
+  if (!q->rg) {  // (the tile form reads both again in spam_csr_values_changed; the row-group form keeps its own source map)
+    q->code = (uint32_t*)code.release();
+    q->slab = (uint8_t*)slab.release();
+  }
   q->res32 = (uint32_t*)res32.release();
   q->sbase_d = (uint64_t*)sbase_d.release();
   if (!q->rg) SPAM_TRY(sliced_dispatch<T>(q, nullptr, s, &q->grid));

@@ -553,8 +553,6 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   if (kn.acc_bits > 0) abits = std::min(abits, kn.acc_bits);
   if (abits < 9) return SPAM_OK;  // tables too wide for the packed word: the caller keeps the tile form
   const uint32_t rmax = (1u << abits) - 1u;  // usable accumulators of a block (+ 1 spare for the padding entries)
-  const uint64_t eblk = (uint64_t)std::max(1024, kn.eblk);
-  const uint64_t ecap = eblk * SPMV_NPART;  // entries of a group over its nine blocks
   const uint64_t max_sub = std::min<uint64_t>(RG_MAX_SUB, rmax / 2);
 
   PhaseClock pc(kn.prof == 4, s);
@@ -595,6 +593,14 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (n_ent == 0 || n_ent >= 0xFFFFFFFFull) return SPAM_OK;
   pc.stamp("    rg: row lengths, masks, rank sort, downloads");
+  // entries of a (part, row group) block.  200 k is the measured optimum when there are thousands of blocks (the bench
+  // matrix: 100 k / 150 k / 200 k / 250 k -> 0.587 / 0.565 / 0.576 / 0.580 ms); smaller matrices need smaller blocks to
+  // give every workgroup several (R-MAT scale 18 .. 21, 4 M .. 32 M entries, 200 k -> 16 k .. 50 k: 87 -> 29, 93 -> 42,
+  // 111 -> 72, 148 -> 116 us; tools/size_sweep.py)
+  const uint64_t n_all_est = n_ent + (res && kn.fold_short ? res->nnz : 0);
+  const uint64_t eblk = kn.eblk > 0 ? (uint64_t)std::max(1024, kn.eblk)
+                                    : std::min<uint64_t>(200000, std::max<uint64_t>(16000, n_all_est / 500));
+  const uint64_t ecap = eblk * SPMV_NPART;  // entries of a group over its nine blocks
 
   // -- row groups and tiles (host): consecutive ranks; per part at most rmax accumulators, ecap entries in all.  Ranks
   //    are placed in SLOTS: a group starts on a multiple of 64 slots, so that tile t is slots [64 t, 64 t + 64) ----------

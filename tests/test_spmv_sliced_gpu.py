@@ -176,6 +176,23 @@ def test_auto_mode_keeps_small_matrices_on_the_plain_path(spam, oracle, sliced_e
     assert not info["active"]
 
 
+def test_auto_mode_times_the_row_group_form_on_a_mid_size_matrix(spam, oracle, sliced_env):
+    """x of R-MAT scale 18 (2 MB) fits any L2, and one table would cover it: the tile form is no candidate there, the
+    row-group form is (sorted gathers, sums in LDS) and spam_spmv_prepare decides by timing both — whichever it keeps,
+    the product is right; the block size follows the matrix (4 M entries: 16 k per block, hundreds of blocks)."""
+    sliced_env()
+    os.environ["SPAM_SPMV_SLICED"] = "1"
+    m = synth.rmat(18)
+    off, idx, val = csr_np(m)
+    info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL, expect_active=False)
+    if os.environ["SPAM_SPMV_RG"] == "1":
+        assert info["ms_plain"] > 0 and info["ms_sliced"] > 0, info  # both were timed
+        if info["active"]:
+            assert info["row_groups"]["active"] and info["row_groups"]["blocks"] >= 150, info
+    else:
+        assert not info["active"], info  # the tile form gains from the tables only
+
+
 def test_row_block_view_forced(spam, oracle, sliced_env):
     """A zero-copy row-block view (what a rank holds of a row-sharded matrix: its row_ptr starts inside the parent's
     arrays, a few pad entries in front) through the sliced path."""
