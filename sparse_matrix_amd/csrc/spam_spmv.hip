@@ -1789,16 +1789,15 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
   const int sl_cfg = p->knobs.sliced;
   if (sl_cfg) {
     SlicedPlan* q = nullptr;
-    SPAM_TRY(sliced_analyse<T>(a, p->knobs, sl_cfg == 2, s, &q, want_stats ? &cs : nullptr));
-    pc.stamp("sliced analysis (all of it)");
-    if (q && sl_cfg == 1) {  // keep it only if it is faster on this matrix
-      struct QGuard {
-        SlicedPlan* q;
-        ~QGuard() { if (q) sliced_plan_free(q); }
-      } qg{q};
-      DevBuf xs, ys;
+    DevBuf xs, ys;
+    const T* xt = x;
+    float ms_plain = 0.f;
+    bool plain_is_fast = false;
+    if (sl_cfg == 1 && a->nnz >= (1u << 20)) {
+      // The plain path first: a matrix it already streams at 4.5 TB/s of algorithmic bytes (banded ones: 5.3) has
+      // nothing to gain from tables or LDS accumulators, and building the sliced structure only to discard it would
+      // cost the caller tens to hundreds of milliseconds.
       SPAM_TRY(ys.alloc(a->rows * sizeof(T)));
-      const T* xt = x;
       if (!xt) {
         SPAM_TRY(xs.alloc(a->cols * sizeof(T)));
         fill_const_kernel<T><<<(unsigned)((a->cols + 255) / 256), 256, 0, s>>>((T*)xs.p, a->cols, T(1));
@@ -1806,10 +1805,23 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
         xt = (const T*)xs.p;
       }
       a->spmv_plan = p;  // plain_run reads the plan through the handle
-      int rc = time_runs([&] { return plain_run<T, OffT>(a, row_ptr, xt, (T*)ys.p, s); }, s, &q->ms_plain);
-      if (rc == SPAM_OK) rc = time_runs([&] { return sliced_run<T>(a, q, xt, (T*)ys.p, s); }, s, &q->ms_sliced);
+      const int rc = time_runs([&] { return plain_run<T, OffT>(a, row_ptr, xt, (T*)ys.p, s); }, s, &ms_plain);
       a->spmv_plan = nullptr;
       SPAM_TRY(rc);
+      p->ms_plain = ms_plain;
+      const double bytes = (double)a->nnz * (4.0 + sizeof(T)) + ((double)a->rows + 1) * 4.0 + ((double)a->cols + (double)a->rows) * sizeof(T);
+      plain_is_fast = ms_plain > 0.f && bytes / ((double)ms_plain * 1e-3) >= 4.5e12;
+      pc.stamp("plain path timed");
+    }
+    if (!plain_is_fast) SPAM_TRY(sliced_analyse<T>(a, p->knobs, sl_cfg == 2, s, &q, want_stats ? &cs : nullptr));
+    pc.stamp("sliced analysis (all of it)");
+    if (q && sl_cfg == 1) {  // keep it only if it is faster on this matrix
+      struct QGuard {
+        SlicedPlan* q;
+        ~QGuard() { if (q) sliced_plan_free(q); }
+      } qg{q};
+      q->ms_plain = ms_plain;
+      SPAM_TRY(time_runs([&] { return sliced_run<T>(a, q, xt, (T*)ys.p, s); }, s, &q->ms_sliced));
       SPAM_HIP_TRY(hipStreamSynchronize(s));
       p->ms_plain = q->ms_plain, p->ms_sliced = q->ms_sliced;
       if (q->ms_sliced < 0.97f * q->ms_plain) {

@@ -57,17 +57,25 @@ for name, make in zoo:
     x = (x * 1000).to(dt) if dt == torch.int64 else x.to(dt)
     y = torch.empty(A.rows, dtype=dt, device=dev)
     lens = A.row_ptr[1:] - A.row_ptr[:-1]
-    # (index_add_ takes minutes when millions of entries share one row: segment sums instead; i64 by wrapping prefix sums)
-    acc = torch.float64 if dt != torch.int64 else torch.int64
-    prod = A.vals.to(acc) * x[A.col_idx.to(torch.int64)].to(acc)
+    # reference: hipSPARSE through torch.sparse in f64 (index_add_ takes minutes when millions of entries share one row, and
+    # torch.segment_reduce returned wrong sums for 20 M segments); i64 by wrapping prefix sums
     if dt == torch.int64:
+        prod = A.vals * x[A.col_idx.to(torch.int64)]
         ps = torch.zeros(A.nnz + 1, dtype=torch.int64, device=dev)
         torch.cumsum(prod, 0, out=ps[1:])
         ref = ps[A.row_ptr[1:]] - ps[A.row_ptr[:-1]]
-        del ps
+        del ps, prod
     else:
-        ref = torch.segment_reduce(prod, "sum", lengths=lens, unsafe=True)
-    del prod
+        S = torch.sparse_csr_tensor(A.row_ptr, A.col_idx.to(torch.int64), A.vals.to(torch.float64), size=(A.rows, A.cols))
+        ref = S @ x.to(torch.float64)
+        del S
+        if not bool(torch.isfinite(ref).all()):  # (seen on the f32 power-law case: non-finite sums from torch.sparse)
+            prod = A.vals.to(torch.float64) * x[A.col_idx.to(torch.int64)].to(torch.float64)
+            ps = torch.zeros(A.nnz + 1, dtype=torch.float64, device=dev)
+            torch.cumsum(prod, 0, out=ps[1:])
+            ref = ps[A.row_ptr[1:]] - ps[A.row_ptr[:-1]]  # prefix sums: good to ~1e-9 relative here
+            del ps, prod
+            name += " (ref: prefix sums)"
     esz = A.vals.element_size()
     nbytes = A.nnz * (4 + esz) + (A.rows + 1) * 4 + A.cols * esz + A.rows * esz
     dA = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, A.vals, True)
@@ -78,6 +86,7 @@ for name, make in zoo:
     torch.cuda.synchronize()
     tp = time.perf_counter() - tp
     t1 = timed(dA, x, y, reps)
+    assert bool(torch.isfinite(y.to(torch.float64)).all()) if dt != torch.int64 else True, "non-finite y"
     if dt == torch.int64:
         err = float((y != ref).sum())
     else:
