@@ -147,8 +147,9 @@ int spam_spmv_i64(const spam_csr* a, const int64_t* x_host, int64_t* y_host);
 int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y);
 /* The analysis step (CSR-adaptive's row binning; here: row -> tile map, hot-column table, XCD-sliced structure), done
  * ONCE per matrix and never inside spam_spmv_*: reads the SPAM_SPMV_* environment knobs, synchronises with the host,
- * and — when the matrix qualifies for the XCD-sliced path — times three SpMVs of either path on d_x (NULL: a vector of
- * ones) and keeps the faster (the sliced one must win by 3 %).  The choice fixes the summation order of later SpMVs on
+ * and — from a million entries on — times three SpMVs of the plain path on d_x (NULL: a vector of ones); unless that
+ * already streams the matrix at 4.5 TB/s (banded matrices do), it builds the XCD-sliced structure where the matrix
+ * qualifies, times it the same way and keeps the faster (the sliced one must win by 3 %).  The choice fixes the summation order of later SpMVs on
  * this handle.  A handle that was never prepared multiplies through the plain tile path without hot-column table: its
  * first SpMV only adds one small kernel (no analysis, no timing), so a one-shot y = A x costs one pass over A.
  * Prepare again after changing the knobs; not to be called while SpMVs on this handle are being queued elsewhere. */
