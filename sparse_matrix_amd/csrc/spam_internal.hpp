@@ -165,7 +165,9 @@ struct RgPlan {
   unsigned grid = 0;
   uint64_t stream_bytes = 0, entries = 0, padded = 0, naccs = 0, npairs = 0, nonempty_blocks = 0;
   unsigned char* stream = nullptr;  // the blocks' chunks, part-major
-  void* blk = nullptr;              // RgBlk[NPART * ng + ngs + 1]: block descriptors
+  void* blk = nullptr;              // RgBlk[NPART * ng + ngs + 1]: block descriptors (plan layout: fill / refresh)
+  void* qblk = nullptr;             // RgBlk[nq]: the kernel's queue entries (a block, or a piece of one), queue by queue
+  uint32_t nq = 0, qbase[SPMV_NPART + 1] = {0}, qcount[SPMV_NPART + 1] = {0};
   uint64_t* pe = nullptr;           // u64[blocks + 1]: padded entries before every block
   uint32_t* sub_head = nullptr;     // u32[naccs - npairs]: head of every extra accumulator
   uint32_t* slot_rows = nullptr;    // u32[64 ntiles]: row of every rank slot (0xFFFFFFFF: none)

@@ -80,9 +80,15 @@ struct RgBlk {
   uint64_t cp0;      // first pair of the block in cp (short-row blocks: first short row)
   uint32_t nchunks;  // 0: nothing to do
   uint32_t nheads;   // pairs of the block = head accumulators (short-row blocks: rows)
-  uint32_t nsubs;    // extra accumulators behind the heads
+  uint32_t nsubs;    // extra accumulators behind the heads; bit 31 (queue entries only): a PIECE of a block, see RG_PIECE
   uint32_t sub0;     // their heads: sub_head[sub0 ..)
 };
+// A block of a few rows and very many entries (a row longer than a whole group's share: its group holds little else) would
+// keep one workgroup busy long after the others are done.  The kernel's queue therefore lists such a block as several
+// PIECES — consecutive chunk ranges of the same block, same accumulators — whose sums are ADDED to the block's pairs by
+// device-scope atomics (a handful of values per piece); the reduce kernel sets those pairs back to zero once it has read them.
+constexpr uint32_t RG_PIECE = 0x80000000u;
+constexpr uint32_t RG_PIECE_MAX_HEADS = 64;
 static_assert(sizeof(RgBlk) == 32, "RgBlk layout");
 
 // Tile t = rank slots [64 t, 64 t + 64), all of one group (a group starts on a multiple of 64: the slots skipped in
@@ -90,23 +96,23 @@ static_assert(sizeof(RgBlk) == 32, "RgBlk layout");
 struct RgTile {
   uint32_t grp;
   uint16_t base[SPMV_NPART];  // pairs of the group's earlier tiles, per part
-  uint16_t pad;
+  uint16_t clear;             // 1: the group has blocks run in pieces — the reduce zeroes the pairs it has read
 };
 static_assert(sizeof(RgTile) == 24, "RgTile layout");
 
 template <class T>
 struct RgArgs {
-  const RgBlk* blk;
+  const RgBlk* blk;           // the queue entries: part-major, the short-row blocks behind them
+  uint32_t qbase[SPMV_NPART + 1], qcount[SPMV_NPART + 1];  // entries [qbase[q], qbase[q] + qcount[q]) belong to queue q
   const uint32_t* sub_head;   // per extra accumulator: the head (block-local) it is folded into
   const unsigned char* stream;
   const T* base[SPMV_NPART];  // gather source of every part: the slab tables, x for the cold part
   T* cp;                      // the pair sums
   uint32_t* queue;            // NPART + 1 heads, SPMV_HEAD_STRIDE words apart (reset by sliced_build_tables_kernel)
-  uint32_t ng, abits;
-  // short rows: block 9 * ng + gs holds short rows [cp0, cp0 + nheads), all their entries; y[short_rows[.]] directly
+  uint32_t abits;
+  // short rows: a block of queue 9 holds short rows [cp0, cp0 + nheads), all their entries; y[short_rows[.]] directly
   T* y;
   const uint32_t* short_rows;
-  uint32_t ngs;
   unsigned long long* times;  // diagnostics (SPAM_SPMV_PROF=3): per block 4 wall-clock stamps (100 MHz); else null
 };
 
@@ -219,15 +225,16 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
     const uint32_t g = __builtin_amdgcn_readfirstlane(s_blk);
     __syncthreads();
     const bool is_short = part == RG_SHORT;
-    if (g >= (is_short ? P.ngs : P.ng)) {
+    if (g >= P.qcount[part]) {
       if (++q > SPMV_NSLAB + 1) break;
       continue;
     }
-    const RgBlk* bd = P.blk + ((uint64_t)part * P.ng + g);
+    const RgBlk* bd = P.blk + (P.qbase[part] + g);
     const uint32_t nchunks = bd->nchunks;
     if (nchunks == 0) continue;  // no entry of this group in this part (its pairs, if any, stay zero)
     const uint64_t off = bd->off, cp0 = bd->cp0;
-    const uint32_t nheads = bd->nheads, nsubs = bd->nsubs, sub0 = bd->sub0;
+    const uint32_t nheads = bd->nheads, nsubs = bd->nsubs & ~RG_PIECE, sub0 = bd->sub0;
+    const bool piece = (bd->nsubs & RG_PIECE) != 0u;
     const uint32_t na = nheads + nsubs;
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     if (P.times) t0 = wall_clock64();
@@ -248,13 +255,17 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
       const uint32_t* sr = P.short_rows + cp0;
 #pragma unroll 4
       for (uint32_t i = threadIdx.x; i < nheads; i += NT) P.y[sr[i]] = (T)acc[i];
+    } else if (piece) {  // (uniform) the other pieces of the block may run on other XCDs: device scope
+      T* out = P.cp + cp0;
+      for (uint32_t i = threadIdx.x; i < nheads; i += NT)
+        __hip_atomic_fetch_add(out + i, (T)acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       T* out = P.cp + cp0;
       for (uint32_t i = threadIdx.x; i < nheads; i += NT) out[i] = (T)acc[i];
     }
     __syncthreads();
     if (P.times && threadIdx.x == 0) {
-      unsigned long long* t = P.times + 4ull * ((uint64_t)part * P.ng + g);
+      unsigned long long* t = P.times + 4ull * ((uint64_t)P.qbase[part] + g);
       t[0] = t0, t[1] = t1, t[2] = t2, t[3] = wall_clock64();
     }
   }
@@ -270,7 +281,7 @@ template <class T>
 __global__ __launch_bounds__(256) void spmv_rg_reduce_kernel(const RgTile* __restrict__ tiles, uint32_t ntiles,
                                                              const uint16_t* __restrict__ mask_slot,
                                                              const uint32_t* __restrict__ slot_rows,
-                                                             const uint64_t* __restrict__ grp_cp, const T* __restrict__ cp,
+                                                             const uint64_t* __restrict__ grp_cp, T* __restrict__ cp,
                                                              T* __restrict__ y) {
   // (the tile index is wave-uniform: as a scalar, the descriptor and the nine block bases are scalar loads and leave the
   // vector-memory pipeline to the masks, rows, pairs and the store)
@@ -289,6 +300,7 @@ __global__ __launch_bounds__(256) void spmv_rg_reduce_kernel(const RgTile* __res
     const uint64_t bal = __ballot(has);
     const uint64_t at = gc[p] + tl.base[p] + (uint64_t)__popcll(bal & lt);
     v[p] = has ? cp[at] : T(0);
+    if (tl.clear && has) cp[at] = T(0);  // (uniform flag) pairs that pieces add to start the next product from zero
   }
   T s = v[0];
 #pragma unroll
@@ -536,7 +548,7 @@ int sort_u32_desc(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t
 
 void rg_plan_free(RgPlan* g) {
   if (!g) return;
-  void* ptrs[] = {g->stream, g->blk, g->pe, g->sub_head, g->slot_rows, g->mask_slot, g->tiles, g->grp_cp, g->cp, g->vsrc};
+  void* ptrs[] = {g->stream, g->blk, g->qblk, g->pe, g->sub_head, g->slot_rows, g->mask_slot, g->tiles, g->grp_cp, g->cp, g->vsrc};
   for (void* p : ptrs)
     if (p) dev_free(p);
   delete g;
@@ -836,8 +848,43 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
     nonempty += cnt != 0;
   }
   h_blk[nb].off = off;
-  g->stream_bytes = off, g->padded = h_pe[nb], g->nonempty_blocks = nonempty;
-  DevBuf pe, stream, vsrc, sub_head, grp_cp, cp;
+  g->stream_bytes = off, g->padded = h_pe[nb];
+  // the kernel's queues: the blocks part by part, a block of few rows and many entries as pieces (RG_PIECE)
+  std::vector<RgBlk> h_q;
+  h_q.reserve((size_t)nb + 64);
+  std::vector<char> grp_clear(ng, 0);
+  {
+    const uint32_t piece_chunks = (uint32_t)std::max<uint64_t>(1, eblk / 256);
+    for (uint32_t part = 0; part <= (uint32_t)SPMV_NPART; ++part) {
+      g->qbase[part] = (uint32_t)h_q.size();
+      const uint32_t cnt = part < (uint32_t)SPMV_NPART ? ng : ngs;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const RgBlk d = h_blk[(size_t)part * ng + i];
+        if (part < (uint32_t)SPMV_NPART && d.nheads > 0 && d.nheads <= RG_PIECE_MAX_HEADS && d.nchunks > 2 * piece_chunks) {
+          const uint32_t m = (d.nchunks + piece_chunks - 1) / piece_chunks, per = (d.nchunks + m - 1) / m;
+          const uint64_t cb = rg_chunk_bytes<T>(part >= (uint32_t)SPMV_NSLAB);
+          for (uint32_t c0 = 0; c0 < d.nchunks; c0 += per) {
+            RgBlk e = d;
+            e.off = d.off + (uint64_t)c0 * cb, e.nchunks = std::min(per, d.nchunks - c0), e.nsubs = d.nsubs | RG_PIECE;
+            h_q.push_back(e);
+          }
+          grp_clear[i] = 1;
+        } else {
+          h_q.push_back(d);
+        }
+      }
+      g->qcount[part] = (uint32_t)h_q.size() - g->qbase[part];
+    }
+    for (RgTile& t : h_tiles) t.clear = (uint16_t)grp_clear[t.grp];
+  }
+  g->nq = (uint32_t)h_q.size();
+  nonempty = 0;
+  for (const RgBlk& e : h_q) nonempty += e.nchunks != 0;
+  g->nonempty_blocks = nonempty;
+  DevBuf pe, stream, vsrc, sub_head, grp_cp, cp, qblk;
+  SPAM_TRY(qblk.alloc(((uint64_t)h_q.size() + 1) * sizeof(RgBlk)));
+  SPAM_HIP_TRY(hipMemcpyAsync(qblk.p, h_q.data(), h_q.size() * sizeof(RgBlk), hipMemcpyHostToDevice, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(tiles.p, h_tiles.data(), (uint64_t)ntiles * sizeof(RgTile), hipMemcpyHostToDevice, s));  // (with the clear flags)
   SPAM_TRY(pe.alloc(((uint64_t)nb + 1) * 8));
   SPAM_TRY(stream.alloc(g->stream_bytes + 16));
   SPAM_TRY(vsrc.alloc(g->padded * 4 + 16));
@@ -860,6 +907,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   pc.stamp("    rg: bounds, offsets, stream fill (incl. allocations)");
   g->stream = stream.as<unsigned char>(), stream.release();
   g->blk = blk.release();
+  g->qblk = qblk.release();
   g->pe = pe.as<uint64_t>(), pe.release();
   g->sub_head = sub_head.as<uint32_t>(), sub_head.release();
   g->slot_rows = slot_rows.as<uint32_t>(), slot_rows.release();
@@ -879,14 +927,15 @@ template <class T>
 int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, uint32_t* queue, T* y, const uint32_t* short_rows,
            hipStream_t s) {
   RgArgs<T> P;
-  P.blk = (const RgBlk*)g->blk, P.sub_head = g->sub_head, P.stream = g->stream;
+  P.blk = (const RgBlk*)g->qblk, P.sub_head = g->sub_head, P.stream = g->stream;
+  for (int q = 0; q <= SPMV_NPART; ++q) P.qbase[q] = g->qbase[q], P.qcount[q] = g->qcount[q];
   for (int p = 0; p < SPMV_NSLAB; ++p) P.base[p] = xh + (uint64_t)p * S;
   P.base[SPMV_NSLAB] = x;
-  P.cp = (T*)g->cp, P.queue = queue, P.ng = g->ng, P.abits = g->abits;
-  P.y = y, P.short_rows = short_rows, P.ngs = g->ngs;
+  P.cp = (T*)g->cp, P.queue = queue, P.abits = g->abits;
+  P.y = y, P.short_rows = short_rows;
   P.times = nullptr;
   DevBuf tbuf;
-  const uint64_t nblk = (uint64_t)g->ng * SPMV_NPART + g->ngs;
+  const uint64_t nblk = g->nq;
   if (g->prof == 3) {  // diagnostics: where the workgroups' time goes (one synchronous launch, stderr)
     SPAM_TRY(tbuf.alloc(nblk * 32));
     SPAM_HIP_TRY(hipMemsetAsync(tbuf.p, 0, nblk * 32, s));
@@ -913,7 +962,7 @@ int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, uint32_t* queue
             (unsigned long long)ran, g->grid, span / 100.0, 100 * zero / cap, 100 * stream / cap, 100 * write / cap,
             100 * (cap - zero - stream - write) / cap);
     for (int p = 0; p <= SPMV_NPART; ++p) {
-      const uint64_t b0 = (uint64_t)p * g->ng, b1 = p < SPMV_NPART ? b0 + g->ng : nblk;
+      const uint64_t b0 = g->qbase[p], b1 = b0 + g->qcount[p];
       unsigned long long last = 0;
       double st = 0;
       for (uint64_t b = b0; b < b1; ++b) last = std::max(last, h[4 * b + 3]), st += h[4 * b + 3] ? (double)(h[4 * b + 2] - h[4 * b + 1]) : 0.0;
@@ -921,7 +970,7 @@ int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, uint32_t* queue
     }
   }
   spmv_rg_reduce_kernel<T><<<(g->ntiles + 3) / 4, 256, 0, s>>>((const RgTile*)g->tiles, g->ntiles, g->mask_slot, g->slot_rows,
-                                                              g->grp_cp, (const T*)g->cp, y);
+                                                              g->grp_cp, (T*)g->cp, y);
   SPAM_CHECK_LAUNCH();
   return SPAM_OK;
 }

@@ -359,3 +359,34 @@ def test_spmv_is_legal_under_stream_capture(spam, oracle, sliced_env, prepared):
             assert np.allclose(y.cpu().numpy(), ref1, rtol=1e-12, atol=0), f"replay {rep}"
     finally:
         _lib.check(L.spam_hip_set_stream(torch.cuda.current_stream().cuda_stream))
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.float64, np.float32])
+def test_row_groups_giant_rows_run_as_pieces(spam, oracle, sliced_env, dtype):
+    """A row longer than a whole group's share of entries sits alone in its group: its blocks are listed in the kernel's
+    queue as several pieces, whose sums meet in the block's pairs by device-scope atomics; the reduce sets those pairs
+    back to zero, so the second and third product of a handle give the same result as the first (i64: bit for bit)."""
+    sliced_env(SLICE_KB=8, RG_EBLK=1024)
+    # 1024-entry blocks: a group takes 9216 entries, a row of 30 000 sits alone and its nine blocks (13 chunks each) run in
+    # four pieces; no row has fewer than three entries, so every queue entry beyond 9 per group is a piece
+    m = synth.powerlaw(30000, heavy_every=10000, heavy_nnz=30000, light_nnz=5, dtype=torch.float64)
+    off, idx, val = csr_np(m)
+    rng = np.random.default_rng(31)
+    if dtype == np.int64:
+        val = rng.integers(-2**50, 2**50, idx.size, dtype=np.int64)
+        x = rng.integers(-2**30, 2**30, m.cols, dtype=np.int64)
+    else:
+        val = val.astype(dtype)
+        x = rng.uniform(0.5, 1.5, m.cols).astype(dtype)
+    A = spam.CsrMatrix(m.rows, m.cols, val, idx, off, True)
+    ref = oracle.spmv((off, idx, val if dtype == np.int64 else val.astype(np.float64)), x if dtype == np.int64 else x.astype(np.float64))
+    ys = [A.spmv(x, prepare=(k == 0)) for k in range(3)]
+    info = A.device().spmv_plan_info()["sliced"]
+    if os.environ["SPAM_SPMV_RG"] == "1":
+        g = info["row_groups"]
+        assert g["active"] and g["blocks"] > 9 * g["groups"], ("pieces make more queue entries than (part, group) blocks", g)
+    for y in ys:
+        if dtype == np.int64:
+            assert np.array_equal(y, ref)
+        else:
+            assert np.all(np.abs(y.astype(np.float64) - ref) <= (1e-12 if dtype == np.float64 else 2e-6) * np.abs(ref))
