@@ -27,7 +27,9 @@
 // runs on.  So the analysis deals the most referenced columns over 8 slabs (one packed x-table per XCD), stores
 // the rows of >= long_min entries again as 8 slab CSRs + a cold part, and the persistent, software-pipelined
 // spmv_sliced_pipe_kernel has its workgroups read HW_REG_XCC_ID and pull tiles of their own XCD's slab from a
-// per-XCD queue (then the cold part, then what other XCDs have left, so nothing depends on the placement).
+// per-XCD queue (then the cold part, then what other XCDs have left, so nothing depends on the placement).  That is
+// the TILE form, kept as a deterministic alternative (SPAM_SPMV_RG=0); by default the sliced rows are held in ROW-GROUP
+// form (spam_spmv_rg.hip: accumulators in LDS, entries in table-slot order), which is also a candidate where x fits an L2.
 // Every part yields a partial y over the long rows; sliced_reduce_kernel adds them in part order.  Shorter rows
 // stay in a compact residual CSR (spmv_short_rows_kernel).  The first SpMV on a handle times both paths on the
 // caller's x and keeps the faster one.
@@ -52,7 +54,7 @@ static void sliced_plan_free(SlicedPlan* q);
 
 // Tuning knobs, read from the environment ONCE per plan (spam_spmv_prepare / the first SpMV on a handle).
 struct SpmvKnobs {
-  int npt = 16;          // SPAM_SPMV_NPT        entries per thread of the plain tile kernel (8 / 16)
+  int npt = 0;           // SPAM_SPMV_NPT        entries per thread of the plain tile kernel (8 / 16; 0: by matrix size)
   int nt = 1;            // SPAM_SPMV_NT         non-temporal ja / a stream
   int hot = 2;           // SPAM_SPMV_HOT        0 off, 1 per-lane base select, 2 cold gathers non-temporal
   int hot_kb = 3072;     // SPAM_SPMV_HOT_KB     hot-column table budget (of the 4 MB L2 per XCD)
@@ -709,7 +711,10 @@ static int env_int(const char* name, int dflt) {
 }
 static SpmvKnobs read_knobs() {
   SpmvKnobs k;
-  k.npt = env_int("SPAM_SPMV_NPT", 16) == 8 ? 8 : 16;
+  {
+    const int n = env_int("SPAM_SPMV_NPT", 0);
+    k.npt = n == 8 || n == 16 ? n : 0;  // 0: by the size of the matrix (build_tile_map)
+  }
   k.nt = env_int("SPAM_SPMV_NT", 1);
   k.hot = env_int("SPAM_SPMV_HOT", 2);
   k.hot_kb = k.hot ? env_int("SPAM_SPMV_HOT_KB", 3072) : 0;
@@ -1704,8 +1709,10 @@ static int time_runs(F&& run, hipStream_t s, float* ms_out) {
 // Caller holds the plan's lock (or is the only user of the handle).
 template <class OffT>
 static int build_tile_map(const spam_csr* a, const OffT* row_ptr, SpmvPlan* p, size_t vsize, hipStream_t s) {
-  const uint32_t tile = SPMV_TPB * p->knobs.npt;
-  p->npt = p->knobs.npt;
+  // tiles of 2048 entries give small matrices more workgroups (R-MAT, 0.2 M .. 65 M entries: 13 -> 10, 18 -> 15, 43 -> 36,
+  // 132 -> 124, 536 -> 485 us); from ~100 M entries on 4096 are a little ahead (1257 against 1298 us at 131 M)
+  p->npt = p->knobs.npt ? p->knobs.npt : (a->nnz < 100000000ull ? 8 : 16);
+  const uint32_t tile = SPMV_TPB * (uint32_t)p->npt;
   p->ntiles = (a->nnz + tile - 1) / tile;
   if (a->nnz == 0) return SPAM_OK;
   DevBuf fo, ca;
