@@ -138,3 +138,33 @@ def test_integer_matrix_market_runs_as_i64(spam, oracle, tmp_path):
     C = A * A
     want = oracle.mul_hash((off, idx, val), (off, idx, val), sort_rows=False)
     assert_csr_exact((C.offsets, C.indices, C.vals), want, False)
+
+
+def test_cfg2_full_size_spmv_is_bit_exact_in_i64(spam, oracle):
+    """BASELINE configs[1]'s matrix (10 M rows, ~162.7 M entries) with Wrapping<i64> values of full range: the prepared
+    plan (XCD-sliced, row-group form — the kernels the headline number is measured on) and the unprepared plain path
+    must both equal the oracle BIT FOR BIT over all 10 M rows: integer sums do not depend on the order of the LDS
+    atomics, so this is the one check of the headline path, at its full size, that has no tolerance in it."""
+    from sparse_matrix_amd import DeviceCsr
+    from sparse_matrix_amd.synth import mix64
+
+    dev = torch.device("cuda", 0)
+    A = synth.rmat_rect(10_000_000, 160_000_000, dtype=torch.float64, device=dev, oversample=1.30)
+    vals = mix64(torch.arange(A.nnz, dtype=torch.int64, device=dev) + 12345)          # all 64 bits in use: sums wrap
+    x = mix64(torch.arange(A.cols, dtype=torch.int64, device=dev) * 3 + 777)
+    dA = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, vals, True)
+    y_plain = torch.empty(A.rows, dtype=torch.int64, device=dev)
+    y_prep = torch.empty_like(y_plain)
+    dA.spmv_dev(x.data_ptr(), y_plain.data_ptr())
+    dA.spmv_prepare(x.data_ptr())
+    info = dA.spmv_plan_info()["sliced"]
+    assert info["active"] and info["row_groups"]["active"], info
+    for _ in range(2):  # (twice: nothing a product leaves behind may change the next one)
+        y_prep.fill_(-1)
+        dA.spmv_dev(x.data_ptr(), y_prep.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(y_prep, y_plain)
+    off = A.row_ptr.cpu().numpy().astype(np.uint64)
+    idx = A.col_idx.cpu().numpy().astype(np.uint64)
+    ref = oracle.spmv((off, idx, vals.cpu().numpy()), x.cpu().numpy(), nthreads=oracle.hardware_threads())
+    assert np.array_equal(y_prep.cpu().numpy(), ref)
