@@ -193,6 +193,38 @@ def test_auto_mode_times_the_row_group_form_on_a_mid_size_matrix(spam, oracle, s
         assert not info["active"], info  # the tile form gains from the tables only
 
 
+@pytest.mark.parametrize("kind", ["powerlaw_f32", "tall", "giant_row_i64", "banded"])
+def test_auto_mode_mid_size_shapes(spam, oracle, sliced_env, kind):
+    """Matrices of 3-6 M entries in AUTO mode (no knob set): whatever spam_spmv_prepare keeps after timing its candidates —
+    block size by the matrix, giant rows in pieces, the plain path for the banded one — the product agrees with the oracle."""
+    sliced_env()
+    os.environ["SPAM_SPMV_SLICED"] = "1"
+    if kind == "powerlaw_f32":
+        m = synth.powerlaw(300_000, heavy_every=500, heavy_nnz=4000, light_nnz=6, dtype=torch.float32)
+        off, idx, val = csr_np(m)
+        info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F32_RTOL, expect_active=False)
+    elif kind == "tall":
+        m = synth.random_csr(1_500_000, 200_000, 3.2e6 / (1_500_000 * 200_000), seed=3, signed=False)
+        off, idx, val = csr_np(m)
+        info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL, expect_active=False)
+    elif kind == "giant_row_i64":
+        m = synth.powerlaw(400_000, heavy_every=200_000, heavy_nnz=400_000, light_nnz=7, dtype=torch.float64)
+        off, idx, _ = csr_np(m)
+        rng = np.random.default_rng(2)
+        val = rng.integers(-2**60, 2**60, idx.size, dtype=np.int64)
+        x = rng.integers(-2**60, 2**60, m.cols, dtype=np.int64)
+        A = spam.CsrMatrix(m.rows, m.cols, val, idx, off, True)
+        ref = oracle.spmv((off, idx, val), x)
+        for k in range(3):
+            assert np.array_equal(A.spmv(x, prepare=(k == 0)), ref), k
+        info = A.device().spmv_plan_info()["sliced"]
+    else:
+        m = synth.banded(600_000, 7)
+        off, idx, val = csr_np(m)
+        info = _check(spam, oracle, off, idx, val, m.rows, m.cols, True, F64_RTOL, expect_active=False)
+    assert info["ms_plain"] > 0, info  # the plain path was timed: the matrix is large enough to be a candidate
+
+
 def test_row_block_view_forced(spam, oracle, sliced_env):
     """A zero-copy row-block view (what a rank holds of a row-sharded matrix: its row_ptr starts inside the parent's
     arrays, a few pad entries in front) through the sliced path."""
