@@ -8,6 +8,7 @@
 // Where the reference panics this throws spam::Panic.
 #pragma once
 
+#include <complex>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -26,10 +27,59 @@ inline void check(int status) {
   if (status != SPAM_OK) throw Panic(status, spam_last_error());
 }
 
+// Element types.  The device holds f32, f64 and i64 (= Wrapping<i64>).  The reference's other instantiations reach them
+// from here:
+//   * int8_t / int16_t / int32_t stand for Wrapping<i8> (the type of the reference's own mul_hash test, tests.rs:358),
+//     Wrapping<i16>, Wrapping<i32>: Z/2^64 -> Z/2^k is a ring homomorphism, so the values run as i64 with 64-bit
+//     wrapping on the device and keep their low bits on the way back — exact;
+//   * std::complex<float / double> (the fuzz targets and MatrixType::Complex, lib.rs:428-430): products and sums are
+//     bilinear, C = (Ar Br - Ai Bi) + i (Ar Bi + Ai Br) from four real products over ONE pattern (mul_hash's pattern
+//     depends on the indices only and keeps computed zeros; the four are taken with sorted rows so that their value
+//     arrays line up).  Same result as complex arithmetic up to rounding, at four times the real cost.
+namespace detail {
+template <class T> struct is_complex : std::false_type {};
+template <class R> struct is_complex<std::complex<R>> : std::true_type { typedef R real; };
+template <class T> struct device_type { typedef T type; };
+template <> struct device_type<int8_t> { typedef int64_t type; };
+template <> struct device_type<int16_t> { typedef int64_t type; };
+template <> struct device_type<int32_t> { typedef int64_t type; };
+template <class D, class T>
+std::vector<D> widen(const std::vector<T>& v) { return std::vector<D>(v.begin(), v.end()); }  // (sign-extends)
+template <class T, class D>
+std::vector<T> narrow(const std::vector<D>& v) {
+  std::vector<T> o(v.size());
+  for (size_t i = 0; i < v.size(); ++i) o[i] = (T)(typename std::make_unsigned<D>::type)v[i];  // low bits: Wrapping<T>
+  return o;
+}
+// the typed entry points of one device type
+template <class D> struct Abi;
+template <> struct Abi<double> {
+  static int upload(uint64_t r, uint64_t c, uint64_t n, const uint64_t* o, const uint64_t* i, const double* v, int s, spam_csr** h) { return spam_csr_upload_f64(r, c, n, o, i, v, s, h); }
+  static int numeric(spam_spgemm_plan* p, int sort, uint64_t* o, uint64_t* i, double* v) { return spam_spgemm_numeric_f64(p, sort, o, i, v); }
+  static int spmv(const spam_csr* a, const double* x, double* y) { return spam_spmv_f64(a, x, y); }
+  static int download(const spam_csr* a, uint64_t* o, uint64_t* i, double* v) { return spam_csr_download_f64(a, o, i, v); }
+};
+template <> struct Abi<float> {
+  static int upload(uint64_t r, uint64_t c, uint64_t n, const uint64_t* o, const uint64_t* i, const float* v, int s, spam_csr** h) { return spam_csr_upload_f32(r, c, n, o, i, v, s, h); }
+  static int numeric(spam_spgemm_plan* p, int sort, uint64_t* o, uint64_t* i, float* v) { return spam_spgemm_numeric_f32(p, sort, o, i, v); }
+  static int spmv(const spam_csr* a, const float* x, float* y) { return spam_spmv_f32(a, x, y); }
+  static int download(const spam_csr* a, uint64_t* o, uint64_t* i, float* v) { return spam_csr_download_f32(a, o, i, v); }
+};
+template <> struct Abi<int64_t> {
+  static int upload(uint64_t r, uint64_t c, uint64_t n, const uint64_t* o, const uint64_t* i, const int64_t* v, int s, spam_csr** h) { return spam_csr_upload_i64(r, c, n, o, i, v, s, h); }
+  static int numeric(spam_spgemm_plan* p, int sort, uint64_t* o, uint64_t* i, int64_t* v) { return spam_spgemm_numeric_i64(p, sort, o, i, v); }
+  static int spmv(const spam_csr* a, const int64_t* x, int64_t* y) { return spam_spmv_i64(a, x, y); }
+  static int download(const spam_csr* a, uint64_t* o, uint64_t* i, int64_t* v) { return spam_csr_download_i64(a, o, i, v); }
+};
+}  // namespace detail
+
 template <class T, bool IS_SORTED>
 class CsrMatrix {
-  static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value || std::is_same<T, int64_t>::value,
-                "the HIP back end serves f32 / f64 / Wrapping<i64>; other T keep the reference's CPU path");
+  static constexpr bool kComplex = detail::is_complex<T>::value;
+  typedef typename detail::device_type<T>::type D;  // what the device holds (complex: see real_imag())
+  static constexpr bool kWidened = !std::is_same<T, D>::value;
+  static_assert(kComplex || std::is_same<D, float>::value || std::is_same<D, double>::value || std::is_same<D, int64_t>::value,
+                "element types: f32, f64, i64, i8 / i16 / i32 (as i64), complex<f32 / f64> (as four real products)");
 
  public:
   // CsrMatrix { rows, cols, vals, indices, offsets }  (lib.rs:26-32)
@@ -73,34 +123,46 @@ class CsrMatrix {
   // Matrix::invariants (lib.rs:152-160): 1 and 2 on the host, 3-7 on the device
   bool invariants() const {
     if (indices_.size() != vals_.size() || offsets_.size() != rows_ + 1) return false;
-    int ok = 0;
-    try {
-      check(spam_csr_invariants(device(), &ok));
-    } catch (const Panic& p) {
-      if (p.code == SPAM_E_INVALID || p.code == SPAM_E_INDEX_RANGE) return false;
-      throw;
+    if constexpr (kComplex) {
+      return part(false).invariants();  // (same structure)
+    } else {
+      int ok = 0;
+      try {
+        check(spam_csr_invariants(device(), &ok));
+      } catch (const Panic& p) {
+        if (p.code == SPAM_E_INVALID || p.code == SPAM_E_INDEX_RANGE) return false;
+        throw;
+      }
+      return ok != 0;
     }
-    return ok != 0;
   }
 
   // pub fn mul_hash<const B1: bool, const B2: bool>(&self, rhs: &CsrMatrix<T, B1>) -> CsrMatrix<T, B2>
   template <bool B1, bool B2>
   CsrMatrix<T, B2> mul_hash(const CsrMatrix<T, B1>& rhs) const {
-    spam_spgemm_plan* plan = nullptr;
-    uint64_t nnz = 0;
-    check(spam_spgemm_symbolic(device(), rhs.device(), &plan, &nnz));
-    std::vector<uint64_t> offsets(rows_ + 1), indices(nnz);  // Vec::with_capacity(nnz) (mul_hash.rs:119)
-    std::vector<T> vals(nnz);
-    int st;
-    if constexpr (std::is_same<T, double>::value)
-      st = spam_spgemm_numeric_f64(plan, B2 ? 1 : 0, offsets.data(), indices.data(), vals.data());
-    else if constexpr (std::is_same<T, int64_t>::value)
-      st = spam_spgemm_numeric_i64(plan, B2 ? 1 : 0, offsets.data(), indices.data(), vals.data());
-    else
-      st = spam_spgemm_numeric_f32(plan, B2 ? 1 : 0, offsets.data(), indices.data(), vals.data());
-    spam_spgemm_plan_free(plan);
-    check(st);
-    return CsrMatrix<T, B2>(rows_, rhs.cols(), std::move(vals), std::move(indices), std::move(offsets));
+    if constexpr (kComplex) {
+      // four real products with sorted rows (a sorted row is one of the orders B2 = false allows)
+      const auto ar = part(false), ai = part(true);
+      const auto br = rhs.part(false), bi = rhs.part(true);
+      auto rr = ar.template mul_hash<B1, true>(br), ii = ai.template mul_hash<B1, true>(bi);
+      auto ri = ar.template mul_hash<B1, true>(bi), ir = ai.template mul_hash<B1, true>(br);
+      if (rr.indices() != ii.indices() || rr.indices() != ri.indices() || rr.indices() != ir.indices() ||
+          rr.offsets() != ii.offsets() || rr.offsets() != ri.offsets() || rr.offsets() != ir.offsets())
+        throw Panic(SPAM_E_INVALID, "the real products of a complex product came back with different patterns");
+      std::vector<T> vals(rr.nnz());
+      for (size_t k = 0; k < vals.size(); ++k) vals[k] = T(rr.vals()[k] - ii.vals()[k], ri.vals()[k] + ir.vals()[k]);
+      return CsrMatrix<T, B2>(rows_, rhs.cols(), std::move(vals), rr.indices(), rr.offsets());
+    } else {
+      spam_spgemm_plan* plan = nullptr;
+      uint64_t nnz = 0;
+      check(spam_spgemm_symbolic(device(), rhs.device(), &plan, &nnz));
+      std::vector<uint64_t> offsets(rows_ + 1), indices(nnz);  // Vec::with_capacity(nnz) (mul_hash.rs:119)
+      std::vector<D> vals(nnz);
+      const int st = detail::Abi<D>::numeric(plan, B2 ? 1 : 0, offsets.data(), indices.data(), vals.data());
+      spam_spgemm_plan_free(plan);
+      check(st);
+      return CsrMatrix<T, B2>(rows_, rhs.cols(), from_device(std::move(vals)), std::move(indices), std::move(offsets));
+    }
   }
 
   // impl Mul for &CsrMatrix<T, B>  ->  CsrMatrix<T, false>  (lib.rs:292-297)
@@ -112,55 +174,85 @@ class CsrMatrix {
   CsrMatrix<T, true> operator-(const CsrMatrix& rhs) const { return ewise(rhs, 1); }
 
   // the SpMV analysis on the uploaded copy (spam_spmv_prepare): worth it when the matrix is multiplied many times
-  void spmv_prepare() const { check(spam_spmv_prepare(const_cast<spam_csr*>(device()), nullptr)); }
+  void spmv_prepare() const {
+    static_assert(!kComplex, "prepare the real and imaginary parts through spmv(): complex matrices hold no handle");
+    check(spam_spmv_prepare(const_cast<spam_csr*>(device()), nullptr));
+  }
 
   // y = A x (absent upstream; mul_hash with an n x 1 right-hand side)
   std::vector<T> spmv(const std::vector<T>& x) const {
     if (x.size() != cols_) throw Panic(SPAM_E_INVALID, "x.len() != cols");
-    std::vector<T> y(rows_);
-    if constexpr (std::is_same<T, double>::value)
-      check(spam_spmv_f64(device(), x.data(), y.data()));
-    else if constexpr (std::is_same<T, int64_t>::value)
-      check(spam_spmv_i64(device(), x.data(), y.data()));
-    else
-      check(spam_spmv_f32(device(), x.data(), y.data()));
-    return y;
+    if constexpr (kComplex) {  // y = (Ar xr - Ai xi) + i (Ar xi + Ai xr)
+      typedef typename detail::is_complex<T>::real R;
+      std::vector<R> xr(x.size()), xi(x.size());
+      for (size_t k = 0; k < x.size(); ++k) xr[k] = x[k].real(), xi[k] = x[k].imag();
+      const auto ar = part(false), ai = part(true);
+      const auto rr = ar.spmv(xr), ii = ai.spmv(xi), ri = ar.spmv(xi), ir = ai.spmv(xr);
+      std::vector<T> y(rows_);
+      for (size_t k = 0; k < y.size(); ++k) y[k] = T(rr[k] - ii[k], ri[k] + ir[k]);
+      return y;
+    } else {
+      std::vector<D> y(rows_);
+      if constexpr (kWidened) {
+        const std::vector<D> xd = detail::widen<D>(x);
+        check(detail::Abi<D>::spmv(device(), xd.data(), y.data()));
+      } else {
+        check(detail::Abi<D>::spmv(device(), x.data(), y.data()));
+      }
+      return from_device(std::move(y));
+    }
   }
 
   // the uploaded copy (created on first use, owned by this object)
   const spam_csr* device() const {
+    static_assert(!kComplex, "a complex matrix holds no device handle of its own: see part()");
     if (!dev_) {
-      if constexpr (std::is_same<T, double>::value)
-        check(spam_csr_upload_f64(rows_, cols_, indices_.size(), offsets_.data(), indices_.data(), vals_.data(),
-                                  IS_SORTED, &dev_));
-      else if constexpr (std::is_same<T, int64_t>::value)
-        check(spam_csr_upload_i64(rows_, cols_, indices_.size(), offsets_.data(), indices_.data(), vals_.data(),
-                                  IS_SORTED, &dev_));
-      else
-        check(spam_csr_upload_f32(rows_, cols_, indices_.size(), offsets_.data(), indices_.data(), vals_.data(),
-                                  IS_SORTED, &dev_));
+      if constexpr (kWidened) {
+        const std::vector<D> wide = detail::widen<D>(vals_);
+        check(detail::Abi<D>::upload(rows_, cols_, indices_.size(), offsets_.data(), indices_.data(), wide.data(), IS_SORTED, &dev_));
+      } else {
+        check(detail::Abi<D>::upload(rows_, cols_, indices_.size(), offsets_.data(), indices_.data(), vals_.data(), IS_SORTED, &dev_));
+      }
     }
     return dev_;
   }
 
+  // complex values: the real (imag = false) or imaginary part as a real matrix over the same pattern
+  auto part(bool imag) const {
+    static_assert(kComplex, "part() is for complex matrices");
+    typedef typename detail::is_complex<T>::real R;
+    std::vector<R> v(vals_.size());
+    for (size_t k = 0; k < v.size(); ++k) v[k] = imag ? vals_[k].imag() : vals_[k].real();
+    return CsrMatrix<R, IS_SORTED>(rows_, cols_, std::move(v), indices_, offsets_);
+  }
+
  private:
+  // device values in this matrix's element type (i64 -> i8 / i16 / i32 keeps the low bits)
+  static std::vector<T> from_device(std::vector<D>&& v) {
+    if constexpr (kWidened) return detail::narrow<T>(v);
+    else return std::move(v);
+  }
   CsrMatrix<T, true> ewise(const CsrMatrix& rhs, int subtract) const {
-    spam_csr* c = nullptr;
-    check(spam_csr_add(device(), rhs.device(), subtract, &c));
-    uint64_t rows = 0, cols = 0, nnz = 0;
-    check(spam_csr_dims(c, &rows, &cols, &nnz, nullptr, nullptr));
-    std::vector<uint64_t> offsets(rows + 1), indices(nnz);
-    std::vector<T> vals(nnz);
-    int st;
-    if constexpr (std::is_same<T, double>::value)
-      st = spam_csr_download_f64(c, offsets.data(), indices.data(), vals.data());
-    else if constexpr (std::is_same<T, int64_t>::value)
-      st = spam_csr_download_i64(c, offsets.data(), indices.data(), vals.data());
-    else
-      st = spam_csr_download_f32(c, offsets.data(), indices.data(), vals.data());
-    spam_csr_free(c);
-    check(st);
-    return CsrMatrix<T, true>(rows, cols, std::move(vals), std::move(indices), std::move(offsets));
+    if constexpr (kComplex) {  // (a + ib) +- (c + id), part by part; zeros are kept, so one pattern
+      auto re = subtract ? part(false) - rhs.part(false) : part(false) + rhs.part(false);
+      auto im = subtract ? part(true) - rhs.part(true) : part(true) + rhs.part(true);
+      if (re.indices() != im.indices() || re.offsets() != im.offsets())
+        throw Panic(SPAM_E_INVALID, "the real sums of a complex sum came back with different patterns");
+      std::vector<T> vals(re.nnz());
+      for (size_t k = 0; k < vals.size(); ++k) vals[k] = T(re.vals()[k], im.vals()[k]);
+      return CsrMatrix<T, true>(rows_, cols_, std::move(vals), re.indices(), re.offsets());
+    } else {
+      spam_csr* c = nullptr;
+      check(spam_csr_add(device(), rhs.device(), subtract, &c));
+      uint64_t rows = 0, cols = 0, nnz = 0;
+      check(spam_csr_dims(c, &rows, &cols, &nnz, nullptr, nullptr));
+      std::vector<uint64_t> offsets(rows + 1), indices(nnz);
+      std::vector<D> vals(nnz);
+      const int st = detail::Abi<D>::download(c, offsets.data(), indices.data(), vals.data());
+      spam_csr_free(c);
+      check(st);
+      return CsrMatrix<T, true>(rows, cols, from_device(std::move(vals)), std::move(indices), std::move(offsets));
+    }
   }
   void release() {
     if (dev_) spam_csr_free(dev_);

@@ -1,9 +1,113 @@
 // C++ host-side smoke test of include/spam_csr.hpp against libspam_hip.so (run by tests/test_cxx_host_gpu.py).
 // Mirrors the reference's identity / mul_hash usage: I*A == A, (A*A) has the banded pattern, spmv(A, 1) = row sums.
+#include <cmath>
+#include <complex>
 #include <cstdio>
 #include <vector>
 
 #include "spam_csr.hpp"
+
+// The reference's other element types through the C++ mirror: Wrapping<i8> (tests.rs:358) runs as i64 and keeps its low
+// byte — compared EXACTLY with the triple loop (spam_dok/src/lib.rs:206-233) in 8-bit wrapping arithmetic; Complex<f64>
+// runs as four real products — compared with the triple loop in complex arithmetic.
+namespace {
+struct Lcg {
+  uint64_t s;
+  uint32_t next() { return (uint32_t)((s = s * 6364136223846793005ull + 1442695040888963407ull) >> 33); }
+};
+template <class T, class Draw>
+spam::CsrMatrix<T, true> random_csr(uint64_t rows, uint64_t cols, unsigned fill_pct, Lcg& g, Draw draw, std::vector<T>* dense,
+                                    std::vector<char>* present) {
+  std::vector<T> vals;
+  std::vector<uint64_t> idx, off{0};
+  dense->assign(rows * cols, T(0)), present->assign(rows * cols, 0);
+  for (uint64_t i = 0; i < rows; ++i) {
+    for (uint64_t j = 0; j < cols; ++j)
+      if (g.next() % 100 < fill_pct) {
+        const T v = draw(g);
+        idx.push_back(j), vals.push_back(v);
+        (*dense)[i * cols + j] = v, (*present)[i * cols + j] = 1;
+      }
+    off.push_back(idx.size());
+  }
+  return spam::CsrMatrix<T, true>(rows, cols, vals, idx, off);
+}
+int8_t wrap8(int v) { return (int8_t)(uint8_t)(unsigned)v; }
+
+int other_element_types() {
+  Lcg g{12345};
+  for (int rep = 0; rep < 20; ++rep) {
+    const uint64_t l = 1 + g.next() % 24, m = 1 + g.next() % 24, n = 1 + g.next() % 24;
+    // ---- Wrapping<i8>
+    std::vector<int8_t> ad, bd;
+    std::vector<char> ap, bp;
+    auto draw8 = [](Lcg& r) { return (int8_t)(uint8_t)(r.next() & 255u); };  // zeros included: stored entries may be 0
+    auto A = random_csr<int8_t>(l, m, 40, g, draw8, &ad, &ap);
+    auto B = random_csr<int8_t>(m, n, 40, g, draw8, &bd, &bp);
+    auto C = A.mul_hash<true, true>(B);
+    if (!C.invariants()) return std::puts("i8: invariants(C) failed"), 1;
+    uint64_t p = 0;
+    for (uint64_t i = 0; i < l; ++i) {
+      for (uint64_t j = 0; j < n; ++j) {
+        int8_t t = 0;
+        bool any = false;
+        for (uint64_t k = 0; k < m; ++k)
+          if (ap[i * m + k] && bp[k * n + j]) any = true, t = wrap8((int)t + (int)wrap8((int)ad[i * m + k] * (int)bd[k * n + j]));
+        if (!any) continue;  // mul_hash's pattern: the symbolic one, computed zeros kept
+        if (p >= C.nnz() || C.indices()[p] != j || C.vals()[p] != t) return std::printf("i8: C(%llu,%llu) wrong\n", (unsigned long long)i, (unsigned long long)j), 1;
+        ++p;
+      }
+      if (C.offsets()[i + 1] != p) return std::puts("i8: row length wrong"), 1;
+    }
+    std::vector<int8_t> x(m);
+    for (auto& v : x) v = draw8(g);
+    const auto y = A.spmv(x);
+    for (uint64_t i = 0; i < l; ++i) {
+      int8_t t = 0;
+      for (uint64_t k = 0; k < m; ++k) t = wrap8((int)t + (int)wrap8((int)ad[i * m + k] * (int)x[k]));
+      if (y[i] != t) return std::puts("i8: spmv wrong"), 1;
+    }
+    const auto S = A + A;
+    if (S.indices() != A.indices()) return std::puts("i8: A + A pattern"), 1;
+    for (uint64_t q = 0; q < S.nnz(); ++q)
+      if (S.vals()[q] != wrap8(2 * (int)A.vals()[q])) return std::puts("i8: A + A values"), 1;
+    // ---- Complex<f64>
+    typedef std::complex<double> Z;
+    std::vector<Z> zad, zbd;
+    auto drawz = [](Lcg& r) { return Z((double)(r.next() % 2001) / 1000.0 - 1.0, (double)(r.next() % 2001) / 1000.0 - 1.0); };
+    auto ZA = random_csr<Z>(l, m, 40, g, drawz, &zad, &ap);
+    auto ZB = random_csr<Z>(m, n, 40, g, drawz, &zbd, &bp);
+    auto ZC = ZA * ZB;  // CsrMatrix<Z, false>; its rows come out sorted
+    if (!ZC.invariants()) return std::puts("complex: invariants(C) failed"), 1;
+    p = 0;
+    for (uint64_t i = 0; i < l; ++i)
+      for (uint64_t j = 0; j < n; ++j) {
+        Z t(0, 0);
+        double scale = 0;
+        bool any = false;
+        for (uint64_t k = 0; k < m; ++k)
+          if (ap[i * m + k] && bp[k * n + j]) any = true, t += zad[i * m + k] * zbd[k * n + j], scale += std::abs(zad[i * m + k]) * std::abs(zbd[k * n + j]);
+        if (!any) continue;
+        if (p >= ZC.nnz() || ZC.indices()[p] != j || std::abs(ZC.vals()[p] - t) > 1e-13 * scale) return std::puts("complex: C entry wrong"), 1;
+        ++p;
+      }
+    if (p != ZC.nnz()) return std::puts("complex: nnz(C) wrong"), 1;
+    std::vector<Z> zx(m);
+    for (auto& v : zx) v = drawz(g);
+    const auto zy = ZA.spmv(zx);
+    for (uint64_t i = 0; i < l; ++i) {
+      Z t(0, 0);
+      for (uint64_t k = 0; k < m; ++k) t += zad[i * m + k] * zx[k];
+      if (std::abs(zy[i] - t) > 1e-12) return std::puts("complex: spmv wrong"), 1;
+    }
+    const auto ZD = ZA - ZA;
+    if (ZD.indices() != ZA.indices()) return std::puts("complex: A - A lost structure"), 1;
+    for (const Z& v : ZD.vals())
+      if (v != Z(0, 0)) return std::puts("complex: A - A != 0"), 1;
+  }
+  return 0;
+}
+}  // namespace
 
 int main() {
   try {
@@ -47,6 +151,7 @@ int main() {
       threw = p.code == SPAM_E_INVALID;
     }
     if (!threw) return std::puts("dimension mismatch did not panic"), 1;
+    if (int rc = other_element_types()) return rc;
     std::puts("cxx host smoke ok");
     return 0;
   } catch (const spam::Panic& p) {
