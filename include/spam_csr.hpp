@@ -8,8 +8,11 @@
 // Where the reference panics this throws spam::Panic.
 #pragma once
 
+#include <algorithm>
 #include <complex>
 #include <cstdint>
+#include <map>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -111,6 +114,33 @@ class CsrMatrix {
     for (uint64_t i = 0; i < n; ++i) idx[i] = i;
     for (uint64_t i = 0; i <= n; ++i) off[i] = i;
     return CsrMatrix(n, n, std::vector<T>(n, T(1)), std::move(idx), std::move(off));
+  }
+
+  // DokMatrix's entries: BTreeMap<(row, col), T> (spam_dok/src/lib.rs:19-23); zeros are never stored (:171-175)
+  typedef std::map<std::pair<uint64_t, uint64_t>, T> Dok;
+
+  // impl From<DokMatrix<T>> for CsrMatrix<T, true>  (lib.rs:315-334): rows in column order
+  static CsrMatrix from_dok(uint64_t rows, uint64_t cols, const Dok& entries) {
+    static_assert(IS_SORTED, "From<DokMatrix> gives sorted rows; the shuffled constructor takes an rng");
+    return build_from_dok(rows, cols, entries, [](std::vector<std::pair<uint64_t, T>>&) {});
+  }
+  // CsrMatrix::<T, false>::from_dok(dok, rng)  (lib.rs:336-358): every row's entries in a random order
+  template <class Rng>
+  static CsrMatrix from_dok(uint64_t rows, uint64_t cols, const Dok& entries, Rng& rng) {
+    static_assert(!IS_SORTED, "from_dok(dok, rng) builds CsrMatrix<T, false>");
+    return build_from_dok(rows, cols, entries, [&](std::vector<std::pair<uint64_t, T>>& row) {
+      for (size_t i = row.size(); i > 1; --i) std::swap(row[i - 1], row[(size_t)(rng() % i)]);
+    });
+  }
+  // impl From<CsrMatrix> for DokMatrix  (lib.rs:375-384) through set_element: zeros dropped
+  Dok to_dok() const {
+    Dok out;
+    for (uint64_t r = 0; r < rows_; ++r)
+      for (uint64_t p = offsets_[r]; p < offsets_[r + 1]; ++p) {
+        if (vals_[p] != T(0)) out[{r, indices_[p]}] = vals_[p];
+        else out.erase({r, indices_[p]});
+      }
+    return out;
   }
 
   uint64_t rows() const { return rows_; }
@@ -227,6 +257,25 @@ class CsrMatrix {
   }
 
  private:
+  template <class RowOrder>
+  static CsrMatrix build_from_dok(uint64_t rows, uint64_t cols, const Dok& entries, RowOrder&& order) {
+    std::vector<T> vals;
+    std::vector<uint64_t> idx, off(rows + 1, 0);
+    std::vector<std::pair<uint64_t, T>> row;
+    auto it = entries.begin();
+    for (uint64_t r = 0; r < rows; ++r) {
+      row.clear();
+      for (; it != entries.end() && it->first.first == r; ++it) {
+        if (it->first.second >= cols) throw Panic(SPAM_E_INVALID, "IndexError");  // spam_matrix::IndexError
+        if (it->second != T(0)) row.emplace_back(it->first.second, it->second);
+      }
+      order(row);
+      for (const auto& e : row) idx.push_back(e.first), vals.push_back(e.second);
+      off[r + 1] = idx.size();
+    }
+    if (it != entries.end()) throw Panic(SPAM_E_INVALID, "IndexError");
+    return CsrMatrix(rows, cols, std::move(vals), std::move(idx), std::move(off));
+  }
   // device values in this matrix's element type (i64 -> i8 / i16 / i32 keeps the low bits)
   static std::vector<T> from_device(std::vector<D>&& v) {
     if constexpr (kWidened) return detail::narrow<T>(v);

@@ -34,6 +34,43 @@ spam::CsrMatrix<T, true> random_csr(uint64_t rows, uint64_t cols, unsigned fill_
 }
 int8_t wrap8(int v) { return (int8_t)(uint8_t)(unsigned)v; }
 
+// tests.rs:356-371 as written: unsorted CSR operands from DOK maps, mul_hash::<false, false>, the product compared as a
+// zero-dropped DOK map with the DOK triple loop in Wrapping<i8> arithmetic.
+int reference_property_wrapping_i8() {
+  typedef spam::CsrMatrix<int8_t, false> M;
+  Lcg g{777};
+  auto rng = [&]() { return (uint64_t)g.next(); };
+  for (int rep = 0; rep < 60; ++rep) {
+    const uint64_t hi = rep % 3 == 2 ? 24 : 4;
+    const uint64_t l = 1 + g.next() % hi, m = 1 + g.next() % hi, n = 1 + g.next() % hi;
+    auto rand_dok = [&](uint64_t r, uint64_t c) {
+      M::Dok d;
+      for (uint64_t k = g.next() % (2 * r * c + 1); k > 0; --k) {
+        const int8_t v = (int8_t)(uint8_t)(g.next() & 255u);
+        if (v != 0) d[{g.next() % r, g.next() % c}] = v;  // (DokMatrix never stores a zero)
+      }
+      return d;
+    };
+    const M::Dok da = rand_dok(l, m), db = rand_dok(m, n);
+    const M A = M::from_dok(l, m, da, rng), B = M::from_dok(m, n, db, rng);
+    const M C = A.mul_hash<false, false>(B);
+    if (!C.invariants()) return std::puts("P2: invariants(C) failed"), 1;
+    M::Dok want;  // t = t + a[i,k] * b[k,j], k ascending (spam_dok/src/lib.rs:214-229); zeros are not stored
+    for (uint64_t i = 0; i < l; ++i)
+      for (uint64_t j = 0; j < n; ++j) {
+        int8_t t = 0;
+        for (uint64_t k = 0; k < m; ++k) {
+          const auto a = da.find({i, k});
+          const auto b = db.find({k, j});
+          if (a != da.end() && b != db.end()) t = wrap8((int)t + (int)wrap8((int)a->second * (int)b->second));
+        }
+        if (t != 0) want[{i, j}] = t;
+      }
+    if (C.to_dok() != want) return std::printf("P2 (Wrapping<i8>): case %d differs\n", rep), 1;
+  }
+  return 0;
+}
+
 int other_element_types() {
   Lcg g{12345};
   for (int rep = 0; rep < 20; ++rep) {
@@ -152,6 +189,7 @@ int main() {
     }
     if (!threw) return std::puts("dimension mismatch did not panic"), 1;
     if (int rc = other_element_types()) return rc;
+    if (int rc = reference_property_wrapping_i8()) return rc;
     std::puts("cxx host smoke ok");
     return 0;
   } catch (const spam::Panic& p) {
