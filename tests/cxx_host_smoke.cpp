@@ -71,6 +71,48 @@ int reference_property_wrapping_i8() {
   return 0;
 }
 
+// tests.rs `new` (:127-143), `identity` (:145-160), `from_arb_dok` (:179-197) and `add` (:334-354), for both IS_SORTED:
+// every CSR result has its invariants and, converted back to DOK, equals what the DOK side computes (test_commutes).
+int reference_base_cases_and_add() {
+  typedef spam::CsrMatrix<int8_t, false> MU;
+  typedef spam::CsrMatrix<int8_t, true> MS;
+  Lcg g{4242};
+  auto rng = [&]() { return (uint64_t)g.next(); };
+  for (int rep = 0; rep < 40; ++rep) {
+    const uint64_t m = 1 + g.next() % 24, n = 1 + g.next() % 24;
+    const MU nu = MU::new_(m, n);
+    const MS ns = MS::new_(m, n);
+    if (!nu.invariants() || !ns.invariants() || !nu.to_dok().empty() || !ns.to_dok().empty()) return std::puts("new: not the empty DOK"), 1;
+    MS::Dok eye;
+    for (uint64_t i = 0; i < m; ++i) eye[{i, i}] = 1;
+    const MU iu = MU::identity(m);
+    const MS is = MS::identity(m);
+    if (!iu.invariants() || !is.invariants() || iu.to_dok() != eye || is.to_dok() != eye) return std::puts("identity: not DokMatrix::identity"), 1;
+    auto rand_dok = [&]() {
+      MS::Dok d;
+      for (uint64_t k = g.next() % (2 * m * n + 1); k > 0; --k) {
+        const int8_t v = (int8_t)(uint8_t)(g.next() & 255u);
+        if (v != 0) d[{g.next() % m, g.next() % n}] = v;
+      }
+      return d;
+    };
+    const MS::Dok d1 = rand_dok(), d2 = rand_dok();
+    const MU u1 = MU::from_dok(m, n, d1, rng), u2 = MU::from_dok(m, n, d2, rng);
+    const MS s1 = MS::from_dok(m, n, d1), s2 = MS::from_dok(m, n, d2);
+    if (!u1.invariants() || !s1.invariants() || u1.to_dok() != d1 || s1.to_dok() != d1) return std::puts("from_dok: round trip differs"), 1;
+    MS::Dok sum = d1;  // DokMatrix + DokMatrix in Wrapping<i8>; a zero result is not stored
+    for (const auto& e : d2) {
+      const int8_t t = wrap8((int)(sum.count(e.first) ? sum[e.first] : (int8_t)0) + (int)e.second);
+      if (t != 0) sum[e.first] = t;
+      else sum.erase(e.first);
+    }
+    const auto cu = u1 + u2;
+    const auto cs = s1 + s2;
+    if (!cu.invariants() || !cs.invariants() || cu.to_dok() != sum || cs.to_dok() != sum) return std::printf("add: case %d differs\n", rep), 1;
+  }
+  return 0;
+}
+
 int other_element_types() {
   Lcg g{12345};
   for (int rep = 0; rep < 20; ++rep) {
@@ -190,6 +232,7 @@ int main() {
     if (!threw) return std::puts("dimension mismatch did not panic"), 1;
     if (int rc = other_element_types()) return rc;
     if (int rc = reference_property_wrapping_i8()) return rc;
+    if (int rc = reference_base_cases_and_add()) return rc;
     std::puts("cxx host smoke ok");
     return 0;
   } catch (const spam::Panic& p) {
