@@ -65,6 +65,22 @@ def kernel_source_hash(*names) -> str:
     return h.hexdigest()[:16]
 
 
+def _si(n: int) -> str:
+    for div, suf in ((10**9, "G"), (10**6, "M"), (10**3, "k")):
+        if n >= div:
+            v = n / div
+            return (f"{v:.0f}" if abs(v - round(v)) < 0.05 else f"{v:.1f}") + suf
+    return str(n)
+
+
+def spmv_workload_name(rows_arg: int, nnz_arg: int, rows: int, nnz: int) -> str:
+    """The label follows the ARGUMENTS and the matrix that was generated; only the defaults are BASELINE configs[1]."""
+    name = f"csr_spmv_f64_rmat_{_si(rows)}x{_si(rows)}_{_si(nnz_arg)}nnz"
+    if rows_arg == 10_000_000 and nnz_arg == 160_000_000:
+        return name + " (BASELINE configs[1])"
+    return name + f" (NOT a BASELINE config: --spmv-rows {rows_arg} --spmv-nnz {nnz_arg}; generated {nnz} entries)"
+
+
 def verified_traffic(pmc_file: str, sources, want: dict):
     """(bytes per launch, source string) from a PMC summary committed under profiles/ — only if it was taken on the
     same kernel sources and the same workload as this run; (None, reason) otherwise."""
@@ -220,7 +236,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "csr_spmv_f64_rmat_10Mx10M_160Mnnz (BASELINE configs[1])", "rows": A.rows,
+            "config": {"workload": spmv_workload_name(args.spmv_rows, args.spmv_nnz, A.rows, A.nnz), "rows": A.rows,
                        "cols": A.cols, "nnz": A.nnz, "avg_nnz_row": round(stA["avg_nnz_row"], 2),
                        "max_nnz_row": stA["max_nnz_row"], "gflops": round(2 * A.nnz * world / (wall / args.steps) / 1e9, 1),
                        "sharding": ("one matrix row-sharded, x all-gathered every step" if sharded else
@@ -293,6 +309,7 @@ def main():
                                    {"rows": A.rows, "nnz": A.nnz, "plan": plan_mode})
         out["roofline"]["traffic"] = tr
         out["roofline"]["traffic_source"] = src
+        out["roofline"]["traffic_measured_in_this_run"] = False  # always read from profiles/ (a separate --pmc run), or null
         log(f"[spmv] {ms_per_step:.4f} ms/step wall, {kern_ms:.4f} ms device, {achieved:.0f} GB/s "
             f"({100 * achieved / HBM_PEAK_GBPS:.1f}% of 8 TB/s, {100 * achieved / copy_ceiling:.1f}% of the copy ceiling); "
             f"first unprepared SpMV {ms_first:.2f} ms, prepare {ms_prepare:.0f} ms, plan {(plan_bytes or 0) / 1e9:.2f} GB")
@@ -375,10 +392,32 @@ def main():
         torch.cuda.synchronize()
         log(f"[spgemm {scale}] rank block rows [{offs0[rank]},{offs0[rank + 1]}) nnz {blk.nnz} generated in {time.time() - t0:.1f}s")
         xfer = {}
+        # N > 1 on RCCL: the exchange runs BEHIND THE C ABI (libspam_hip_rccl.so: spam_csr_allgather_rccl +
+        # spam_spgemm_rank_step_rccl — what the Rust host calls; torch.distributed only hands the 128-byte unique id
+        # around and provides the bench's barrier).  SPAM_EXCHANGE=torch selects the torch.distributed all_to_all of
+        # dist.py instead (and is what a gloo rehearsal on one GPU uses: RCCL refuses two ranks on one device).
+        use_cabi = world > 1 and backend == "nccl" and os.environ.get("SPAM_EXCHANGE", "cabi") == "cabi"
+        if use_cabi:
+            if comm_box[0] is None:
+                comm_box[0] = spdist.RcclComm.from_torch_dist(dist, rank, world)
+            comm = comm_box[0]
+            shard = DeviceCsr.from_torch(offs0[rank + 1] - offs0[rank], n, blk.row_ptr, blk.col_idx, blk.vals, True)
+
+        def one_step_cabi(sort_rows=False):
+            B, received = comm.allgather_csr(shard, offs0)  # values still in flight: only the numeric phase waits
+            xfer.update({"bytes_received": received, "mode": "C ABI: grouped ncclSend/ncclRecv per peer (libspam_hip_rccl.so)",
+                         "flop_count": "sharded over the ranks' initial row blocks, per-row counts all-gathered (8 B/row)"})
+            C, st, (mylo, myhi) = comm.rank_step(B, B, offs0, spdist.ROW_OVERHEAD_PRODUCTS, sort_rows)
+            if C is None:
+                return None, None
+            C._keep = (C._keep, B)
+            return C, st
 
         def one_step(sort_rows=False):
             """all-gather B (vals in flight during the symbolic phase), flop-balanced row block of A, two-phase SpGEMM.
             Returns (C, stats)."""
+            if use_cabi:
+                return one_step_cabi(sort_rows)
             g = spdist.allgather_csr(blk.row_ptr, blk.col_idx, blk.vals, offs0, rank, world, dist, async_vals=True)
             xfer.update(g.stats)
             g.wait_structure()
@@ -503,6 +542,7 @@ def main():
         _lib.check(L.spam_hip_trim())
         return sg
 
+    comm_box = [None]  # the C-ABI communicator, made once and shared by both products
     if args.spgemm_scale > 0:
         sg = run_spgemm(args.spgemm_scale, args.spgemm_steps, rank == 0 and world == 1 and not args.no_cpu_baseline)
         out["spgemm"] = sg

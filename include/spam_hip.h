@@ -42,6 +42,7 @@ extern "C" {
 #define SPAM_E_OVERFLOW 5    /* checked_add overflow (mul_hash.rs:47-48, lib.rs:270) */
 #define SPAM_E_UNSUPPORTED 6 /* valid request this build cannot serve (message says why) */
 #define SPAM_E_DTYPE 7       /* entry point of one value type called on a handle of another */
+#define SPAM_E_COMM 8        /* RCCL error in libspam_hip_rccl.so (spam_hip_rccl.h; message has ncclGetErrorString) */
 
 #define SPAM_F32 0
 #define SPAM_F64 1
@@ -234,6 +235,15 @@ int spam_rows_to_parts(const spam_csr* a, const spam_csr* b, uint64_t nparts, ui
  * than a block of few heavy rows with equal F (measured: a non-empty row costs about 4000 products; 2300 with the round-1 kernels). */
 int spam_rows_to_parts_weighted(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t row_overhead,
                                 uint64_t* rows_offset_out /* nparts+1 */);
+
+/* The two halves of rows_to_threads, device-resident, for hosts that spread the flop count over the ranks (the
+ * multi-GPU step of libspam_hip_rccl.so does): (1) mul_hash.rs:39-50 for rows [row_lo, row_hi) of A only — reads A's row
+ * range and B's row_ptr, writes d_flops_out[0 .. row_hi - row_lo) in HBM; SPAM_E_OVERFLOW where checked_add would panic
+ * (partial sums of 2^60 and more are refused, so that the sum over up to 8 ranks' shares still fits);
+ * (2) mul_hash.rs:51-62 on a device vector of per-row counts (+ row_overhead per non-empty row, see above). */
+int spam_row_flops_dev(const spam_csr* a, const spam_csr* b, uint64_t row_lo, uint64_t row_hi, uint64_t* d_flops_out);
+int spam_rows_to_parts_from_flops_dev(const uint64_t* d_row_flops, uint64_t rows, uint64_t nparts, uint64_t row_overhead,
+                                      uint64_t* rows_offset_out /* nparts+1, host */);
 
 #ifdef __cplusplus
 }

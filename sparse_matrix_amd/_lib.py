@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libspam_hip.so")
 SPAM_OK = 0
 SPAM_F32, SPAM_F64, SPAM_I64 = 0, 1, 2
 ERR_NAMES = {1: "SPAM_E_INVALID", 2: "SPAM_E_INDEX_RANGE", 3: "SPAM_E_OOM", 4: "SPAM_E_HIP",
-             5: "SPAM_E_OVERFLOW", 6: "SPAM_E_UNSUPPORTED", 7: "SPAM_E_DTYPE"}
+             5: "SPAM_E_OVERFLOW", 6: "SPAM_E_UNSUPPORTED", 7: "SPAM_E_DTYPE", 8: "SPAM_E_COMM"}
 DTYPE_SUFFIX = {0: "f32", 1: "f64", 2: "i64"}
 
 
@@ -94,9 +94,44 @@ SYMBOLS = {
                                         C.POINTER(SpgemmStats)]),
     "spam_rows_to_parts": (C.c_int, [_P, _P, _U64, _P, _P]),
     "spam_rows_to_parts_weighted": (C.c_int, [_P, _P, _U64, _U64, _P]),
+    "spam_row_flops_dev": (C.c_int, [_P, _P, _U64, _U64, _P]),
+    "spam_rows_to_parts_from_flops_dev": (C.c_int, [_P, _U64, _U64, _U64, _P]),
 }
 
+# every symbol include/spam_hip_rccl.h declares (libspam_hip_rccl.so: links RCCL; loaded only by multi-GPU hosts)
+SYMBOLS_RCCL = {
+    "spam_rccl_unique_id": (C.c_int, [_P]),
+    "spam_rccl_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _PP]),
+    "spam_rccl_comm_adopt": (C.c_int, [_P, C.c_int, C.c_int, _PP]),
+    "spam_rccl_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "spam_rccl_last_exchange": (C.c_int, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
+    "spam_rccl_comm_free": (None, [_P]),
+    "spam_csr_allgather_rccl": (C.c_int, [_P, _P, _P, _PP]),
+    "spam_vector_allgather_rccl": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "spam_spgemm_rank_step_rccl": (C.c_int, [_P, _P, _P, _P, _U64, C.c_int, _PP, C.POINTER(_U64), C.POINTER(_U64),
+                                             C.POINTER(SpgemmStats)]),
+}
+RCCL_ID_BYTES = 128
+LIB_RCCL_PATH = os.path.join(_HERE, "libspam_hip_rccl.so")
+
 _lib = None
+_lib_rccl = None
+
+
+def load_rccl():
+    """Load libspam_hip_rccl.so (RCCL exchange behind the C ABI) and bind every declared symbol."""
+    global _lib_rccl
+    if _lib_rccl is None:
+        load()  # libspam_hip.so first: the sibling resolves its symbols against the copy already mapped
+        if not os.path.exists(LIB_RCCL_PATH):
+            raise ImportError(f"{LIB_RCCL_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(LIB_RCCL_PATH)
+        for name, (res, args) in SYMBOLS_RCCL.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib_rccl = lib
+    return _lib_rccl
 
 
 def load():

@@ -279,6 +279,7 @@ static int download_impl(const spam_csr* m, int dtype, uint64_t* offsets, uint64
   if (!m) return set_error(SPAM_E_INVALID, "matrix is NULL");
   if (m->dtype != dtype) return set_error(SPAM_E_DTYPE, "handle dtype does not match entry point");
   hipStream_t s = stream();
+  SPAM_TRY(wait_values(m, s));
   if (offsets) SPAM_HIP_TRY(hipMemcpyAsync(offsets, m->row_ptr, (m->rows + 1) * 8, hipMemcpyDeviceToHost, s));
   if (vals && m->nnz) SPAM_HIP_TRY(hipMemcpyAsync(vals, m->vals, m->nnz * sizeof(T), hipMemcpyDeviceToHost, s));
   if (indices && m->nnz) {
@@ -304,7 +305,7 @@ using namespace spam;
 
 extern "C" {
 
-int spam_version(void) { return 1001; }  // 1001: + spmv_prepare, values_changed, rank_step, i64 entry points, copy_gbps
+int spam_version(void) { return 1002; }  // 1001: + spmv_prepare, values_changed, rank_step, i64 entry points, copy_gbps; 1002: + row_flops_dev, rows_to_parts_from_flops_dev, libspam_hip_rccl.so
 
 const char* spam_last_error(void) { return g_err.c_str(); }
 
@@ -486,6 +487,7 @@ int spam_csr_row_block(const spam_csr* a, uint64_t row_lo, uint64_t row_hi, spam
   m->nnz = ends[1] - base;  // the view's arrays start at `base`; entries [base, ends[0]) belong to no row
   m->col_idx = a->col_idx + base;
   m->vals = (char*)a->vals + base * dtype_size(a->dtype);
+  m->vals_ready = a->vals_ready;  // a view of a matrix whose values are still arriving shares its event (not owned)
   DevBuf rp, rp32;
   if (int e = rp.alloc((m->rows + 1) * 8)) {
     delete m;
@@ -530,6 +532,7 @@ int spam_csr_device_ptrs(const spam_csr* m, const uint64_t** d_row_ptr, const ui
                          const void** d_vals) {
   clear_error();
   if (!m) return set_error(SPAM_E_INVALID, "matrix is NULL");
+  if (m->vals_ready && d_vals) SPAM_HIP_TRY(hipEventSynchronize(m->vals_ready));  // raw pointers leave the library: values must be there
   if (d_row_ptr) *d_row_ptr = m->row_ptr;
   if (d_col_idx) *d_col_idx = m->col_idx;
   if (d_vals) *d_vals = m->vals;
@@ -582,6 +585,10 @@ int spam_csr_invariants(const spam_csr* m, int* ok) {
 
 void spam_csr_free(spam_csr* m) {
   if (!m) return;
+  if (m->vals_ready && m->owns_vals_event) {  // the exchange stream may still be writing vals: do not recycle them under it
+    (void)hipEventSynchronize(m->vals_ready);
+    (void)hipEventDestroy(m->vals_ready);
+  }
   if (m->spmv_plan) spmv_plan_free(m->spmv_plan);
   if (m->owns_row_ptr && m->row_ptr) dev_free(m->row_ptr);
   if (m->owns_row_ptr32 && m->row_ptr32) dev_free(m->row_ptr32);

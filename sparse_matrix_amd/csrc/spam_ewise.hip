@@ -119,6 +119,7 @@ static int private_sorted_copy(const spam_csr* m, spam_csr** out) {
   const size_t vs = dtype_size(m->dtype);
   if (int e = ci.alloc(m->nnz * 4)) { delete c; return e; }
   if (int e = va.alloc(m->nnz * vs)) { delete c; return e; }
+  if (int e = wait_values(m, s)) { delete c; return e; }
   hipError_t h1 = hipMemcpyAsync(ci.p, m->col_idx, m->nnz * 4, hipMemcpyDeviceToDevice, s);
   hipError_t h2 = hipMemcpyAsync(va.p, m->vals, m->nnz * vs, hipMemcpyDeviceToDevice, s);
   if (h1 != hipSuccess || h2 != hipSuccess) { delete c; return set_error(SPAM_E_HIP, "device copy failed"); }
@@ -133,6 +134,8 @@ static int private_sorted_copy(const spam_csr* m, spam_csr** out) {
 template <class T>
 static int add_typed(const spam_csr* a, const spam_csr* b, int subtract, spam_csr** out) {
   hipStream_t s = stream();
+  SPAM_TRY(wait_values(a, s));
+  SPAM_TRY(wait_values(b, s));
   const uint32_t rows = (uint32_t)a->rows;
   DevBuf rn, crp, tmp, ccol, cval;
   SPAM_TRY(rn.alloc((uint64_t)rows * 4));

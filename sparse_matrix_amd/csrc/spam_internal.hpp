@@ -114,14 +114,35 @@ struct spam_csr {
   std::mutex plan_mu;                   // serialises its construction (handles may be used from several host threads)
   std::mutex run_mu;  // serialises the ENQUEUE of one SpMV's kernels: they share the plan's scratch (tables, queue heads, pair
                       // sums, carries), which is safe in stream order but not when two threads' launches interleave
+  // Set by spam_csr_allgather_rccl (spam_rccl.hip): `vals` is being filled by the exchange stream and is complete once this
+  // event has fired.  Everything that reads vals on the library stream waits for it first (spam::wait_values); the
+  // symbolic phase and the partition read only row_ptr / col_idx and do not, which is how the transfer of the values
+  // (2/3 of B's bytes) runs under them.  Row-block views share their parent's event.
+  hipEvent_t vals_ready = nullptr;
+  bool owns_vals_event = false;
 };
 
 namespace spam {
 
 inline size_t dtype_size(int dtype) { return dtype == SPAM_F32 ? 4 : 8; }
+// make stream s wait until m's values have arrived (no-op for every handle that was not gathered asynchronously)
+inline int wait_values(const spam_csr* m, hipStream_t s) {
+  if (m && m->vals_ready) SPAM_HIP_TRY(hipStreamWaitEvent(s, m->vals_ready, 0));
+  return SPAM_OK;
+}
 // SPAM_I64 values are computed on their bit pattern as unsigned 64-bit integers: unsigned arithmetic wraps, which IS
 // Wrapping<i64>'s two's-complement behaviour (and keeps the kernels free of signed-overflow undefined behaviour)
 typedef unsigned long long i64w;
+// What an accumulator holds before the first product arrives.  The reference STORES the first product of a column
+// (`or_insert(t1)`, mul_hash.rs:157-161; map.rs:113-116) and adds the later ones; an accumulator that starts at the additive
+// identity and adds every product gives the same value — provided the identity is -0.0, not +0.0: (+0.0) + (-0.0) = +0.0
+// would flip the sign of a first product of -0.0, (-0.0) + x = x for every x.  Integers: 0.
+template <class T>
+__host__ __device__ constexpr T acc_identity() { return T(0); }
+template <>
+__host__ __device__ constexpr double acc_identity<double>() { return -0.0; }
+template <>
+__host__ __device__ constexpr float acc_identity<float>() { return -0.0f; }
 // run f.template operator()<T>() for the value type of a handle
 #define SPAM_DISPATCH_DTYPE(dtype, CALL_F64, CALL_F32, CALL_I64) \
   ((dtype) == SPAM_F64 ? (CALL_F64) : (dtype) == SPAM_F32 ? (CALL_F32) : (CALL_I64))

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(TPB) void num_row_kernel(
     const uint32_t mask = tsize - 1;
     for (uint32_t i = threadIdx.x; i < tsize; i += TPB) {
       keys[i] = EMPTY_KEY;
-      vals[i] = T(0);
+      vals[i] = acc_identity<T>();  // the first add then equals "store the first product" (mul_hash.rs:157-161), -0.0 included
     }
     const uint64_t ps = a_rp[row], pe = a_rp[row + 1];
     for (uint64_t pb = ps; pb < pe; pb += SEG) {
@@ -628,7 +628,7 @@ __global__ __launch_bounds__((G > 256 ? G : 256)) void num_hash_kernel(
     tsize = table_size_for(row_nnz[row]);  // hm.shrink_to(*row_nz) (mul_hash.rs:144)
     for (uint32_t i = gl; i < tsize; i += G) {
       keys[g][i] = EMPTY_KEY;
-      vals[g][i] = T(0);
+      vals[g][i] = acc_identity<T>();  // (-0.0: the first add equals "store the first product", mul_hash.rs:157-161)
     }
   }
   __syncthreads();
@@ -1549,6 +1549,10 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
     const uint32_t c0 = j0 << CW_SHIFT, cspan = (j1 - j0) << CW_SHIFT;
     const uint32_t nwords = cspan >> 5;                       // multiple of 16 * TPB / 32 = TPB / 2: a whole number of
     T* vals = (T*)(region + (size_t)nwords * sizeof(RankWord));  // 64-word steps for every wavefront
+    // float accumulators start at -0.0, the additive identity that keeps the sign of a first product of -0.0 ("store the
+    // first product", mul_hash.rs:157-161); pass 1 touches only the bitmap words, so these writes ride under its loads
+    if constexpr (!std::is_integral<T>::value)
+      for (uint32_t i = threadIdx.x; i < it_c.cnt; i += TPB) vals[i] = acc_identity<T>();
     // prefetch: B-split lookups of the next item (its entries were requested an item ago), entries of the one after
     fetch_range(it_n.j0, it_n.j1, ks_n, los_n, lens_n);
     fetch_range(it_n.j0, it_n.j1, ko_n, loo_n, leno_n);
@@ -1635,7 +1639,7 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
     const uint32_t cnt = it_c.cnt;
     for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
       c_val[out + i] = vals[i];
-      vals[i] = T(0);
+      vals[i] = T(0);  // all-zero bits: the next item lays its bitmap words and values out differently over the same LDS
     }
     // columns: every lane expands its own words (a loop over the word's set bits; adjacent lanes hold adjacent words, so
     // the stores of one step land in one stretch of C).  Two alternatives measured slower: 32 lanes per word with the
@@ -2454,6 +2458,7 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     p->b_val = b->vals;
     if (!b->is_sorted && p->nchunks > 1) {
       // the B pre-split needs sorted rows: sort a private copy once (the reference accepts either, flag B1)
+      SPAM_TRY(wait_values(b, s));
       SPAM_TRY(p->bs_col.alloc(b->nnz * 4));
       SPAM_TRY(p->bs_val.alloc(b->nnz * dtype_size(b->dtype)));
       SPAM_HIP_TRY(hipMemcpyAsync(p->bs_col.p, b->col_idx, b->nnz * 4, hipMemcpyDeviceToDevice, s));
@@ -2568,6 +2573,8 @@ static int numeric_typed(spam_spgemm_plan* p, int sort_rows, spam_csr** c_out) {
   hipStream_t s = stream();
   const uint32_t rows = (uint32_t)a->rows;
   spam_spgemm_stats& st = p->st;
+  SPAM_TRY(wait_values(a, s));  // operands gathered by spam_csr_allgather_rccl: the symbolic phase ran while their values
+  SPAM_TRY(wait_values(b, s));  // were still in flight; the numeric phase is the first reader
   SPAM_HIP_TRY(hipEventRecord(p->ev[3], s));
   DevBuf ccol, cval;
   SPAM_TRY(ccol.alloc(st.nnz_c * 4));
@@ -2824,6 +2831,7 @@ int spam_csr_sort_rows(spam_csr* m) {
   if (m->is_sorted) return SPAM_OK;
   if (!m->owns_col_val) return set_error(SPAM_E_INVALID, "cannot sort a borrowed matrix in place (views, spam_csr_from_device)");
   hipStream_t s = stream();
+  SPAM_TRY(wait_values(m, s));
   SPAM_TRY(SPAM_DISPATCH_DTYPE(m->dtype, sort_rows_typed<double>(m->rows, m->cols, m->row_ptr, m->col_idx, (double*)m->vals, s),
                                sort_rows_typed<float>(m->rows, m->cols, m->row_ptr, m->col_idx, (float*)m->vals, s),
                                sort_rows_typed<i64w>(m->rows, m->cols, m->row_ptr, m->col_idx, (i64w*)m->vals, s)));
@@ -2858,37 +2866,75 @@ int spam_spgemm_dev(const spam_csr* a, const spam_csr* b, int sort_rows, spam_cs
   return e;
 }
 
+// rows_to_threads' partition (mul_hash.rs:51-62) of a device vector of per-row product counts
+static int parts_from_flops(const uint64_t* d_flops, uint64_t rows, uint64_t nparts, uint64_t row_overhead,
+                            uint64_t* rows_offset_out, hipStream_t s) {
+  if (row_overhead >= (1ull << 30)) return set_error(SPAM_E_OVERFLOW, "partition cost would overflow the u64 prefix sums (lib.rs:270)");
+  DevBuf cost, ps, tmp, offs;
+  SPAM_TRY(cost.alloc(rows * 8));
+  SPAM_TRY(ps.alloc((rows + 1) * 8));
+  SPAM_TRY(tmp.alloc(scan_tmp_bytes(rows)));
+  SPAM_TRY(offs.alloc((nparts + 1) * 8));
+  part_cost_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, s>>>(d_flops, rows, row_overhead, cost.as<uint64_t>());
+  SPAM_CHECK_LAUNCH();
+  SPAM_TRY(scan_u64_to_u64(cost.as<uint64_t>(), rows, ps.as<uint64_t>(), tmp.p, s));
+  part_points_kernel<<<(unsigned)((nparts + 1 + 63) / 64), 64, 0, s>>>(ps.as<uint64_t>(), rows, nparts, offs.as<uint64_t>());
+  SPAM_CHECK_LAUNCH();
+  SPAM_HIP_TRY(hipMemcpyAsync(rows_offset_out, offs.p, (nparts + 1) * 8, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  return SPAM_OK;
+}
+
 static int rows_to_parts_impl(const spam_csr* a, const spam_csr* b, uint64_t nparts, uint64_t row_overhead,
                               uint64_t* row_flops_out, uint64_t* rows_offset_out) {
   clear_error();
   if (!rows_offset_out || nparts == 0) return set_error(SPAM_E_INVALID, "bad nparts / NULL output");
   SPAM_TRY(check_pair(a, b));
   hipStream_t s = stream();
-  DevBuf flops, total, cost, ps, tmp, offs;
+  DevBuf flops, total;
   SPAM_TRY(flops.alloc(a->rows * 8));
   SPAM_TRY(total.alloc(16));
   SPAM_TRY(launch_flops(a, b, flops.as<uint64_t>(), total.as<unsigned long long>(), s));
-  SPAM_TRY(cost.alloc(a->rows * 8));
-  SPAM_TRY(ps.alloc((a->rows + 1) * 8));
-  SPAM_TRY(tmp.alloc(scan_tmp_bytes(a->rows)));
-  SPAM_TRY(offs.alloc((nparts + 1) * 8));
-  part_cost_kernel<<<(unsigned)((a->rows + 255) / 256), 256, 0, s>>>(flops.as<uint64_t>(), a->rows, row_overhead,
-                                                                      cost.as<uint64_t>());
-  SPAM_CHECK_LAUNCH();
-  SPAM_TRY(scan_u64_to_u64(cost.as<uint64_t>(), a->rows, ps.as<uint64_t>(), tmp.p, s));
-  part_points_kernel<<<(unsigned)((nparts + 1 + 63) / 64), 64, 0, s>>>(ps.as<uint64_t>(), a->rows, nparts, offs.as<uint64_t>());
-  SPAM_CHECK_LAUNCH();
   unsigned long long htot[2];
   SPAM_HIP_TRY(hipMemcpyAsync(htot, total.p, 16, hipMemcpyDeviceToHost, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(rows_offset_out, offs.p, (nparts + 1) * 8, hipMemcpyDeviceToHost, s));
   if (row_flops_out) SPAM_HIP_TRY(hipMemcpyAsync(row_flops_out, flops.p, a->rows * 8, hipMemcpyDeviceToHost, s));
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   if (htot[1]) return set_error(SPAM_E_OVERFLOW, "intermediate-product count overflows usize (mul_hash.rs:47-48)");
   // the scanned cost adds row_overhead per non-empty row to F: keep the u64 prefix sums of checked_inclusive_scan
   // (lib.rs:267-274) from wrapping (rows < 2^32, so F < 2^63 leaves room for any sane overhead)
-  if (htot[0] >= (1ull << 63) || row_overhead >= (1ull << 30))
-    return set_error(SPAM_E_OVERFLOW, "partition cost would overflow the u64 prefix sums (lib.rs:270)");
+  if (htot[0] >= (1ull << 63)) return set_error(SPAM_E_OVERFLOW, "partition cost would overflow the u64 prefix sums (lib.rs:270)");
+  return parts_from_flops(flops.as<uint64_t>(), a->rows, nparts, row_overhead, rows_offset_out, s);
+}
+
+int spam_row_flops_dev(const spam_csr* a, const spam_csr* b, uint64_t row_lo, uint64_t row_hi, uint64_t* d_flops_out) {
+  clear_error();
+  SPAM_TRY(check_pair(a, b));
+  if (row_lo > row_hi || row_hi > a->rows || (row_hi > row_lo && !d_flops_out))
+    return set_error(SPAM_E_INVALID, "row range [%llu, %llu) outside 0..%llu or NULL output", (unsigned long long)row_lo,
+                     (unsigned long long)row_hi, (unsigned long long)a->rows);
+  if (row_hi == row_lo) return SPAM_OK;
+  hipStream_t s = stream();
+  DevBuf total;
+  SPAM_TRY(total.alloc(16));
+  SPAM_HIP_TRY(hipMemsetAsync(total.p, 0, 16, s));
+  const uint64_t n = row_hi - row_lo;
+  unsigned grid = (unsigned)std::min<uint64_t>((n + 3) / 4, 16384);
+  spgemm_flops_kernel<<<grid, 256, 0, s>>>(a->row_ptr + row_lo, a->col_idx, b->row_ptr, (uint32_t)n, d_flops_out,
+                                           total.as<unsigned long long>());
+  SPAM_CHECK_LAUNCH();
+  unsigned long long htot[2];
+  SPAM_HIP_TRY(hipMemcpyAsync(htot, total.p, 16, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));
+  if (htot[1] || htot[0] >= (1ull << 60))
+    return set_error(SPAM_E_OVERFLOW, "intermediate-product count overflows usize (mul_hash.rs:47-48)");
   return SPAM_OK;
+}
+
+int spam_rows_to_parts_from_flops_dev(const uint64_t* d_row_flops, uint64_t rows, uint64_t nparts, uint64_t row_overhead,
+                                      uint64_t* rows_offset_out) {
+  clear_error();
+  if (!d_row_flops || !rows_offset_out || nparts == 0 || rows == 0) return set_error(SPAM_E_INVALID, "bad nparts / rows / NULL argument");
+  return parts_from_flops(d_row_flops, rows, nparts, row_overhead, rows_offset_out, stream());
 }
 
 int spam_spgemm_rank_step(const spam_csr* a_full, const spam_csr* b_full, uint64_t rank, uint64_t world,

@@ -1859,6 +1859,7 @@ static int spmv_launch_t(const spam_csr* a, const void* d_x, void* d_y, hipStrea
   return spmv_typed<T, uint64_t>(a, a->row_ptr, (const T*)d_x, (T*)d_y, s);
 }
 int spmv_launch(const spam_csr* a, const void* d_x, void* d_y, hipStream_t s) {
+  SPAM_TRY(wait_values(a, s));
   return SPAM_DISPATCH_DTYPE(a->dtype, spmv_launch_t<double>(a, d_x, d_y, s), spmv_launch_t<float>(a, d_x, d_y, s),
                              spmv_launch_t<i64w>(a, d_x, d_y, s));
 }
@@ -1869,6 +1870,7 @@ static int spmv_prepare_t(spam_csr* a, const void* d_x, hipStream_t s) {
   return prepare_typed<T, uint64_t>(a, a->row_ptr, (const T*)d_x, s);
 }
 static int spmv_prepare(spam_csr* a, const void* d_x, hipStream_t s) {
+  SPAM_TRY(wait_values(a, s));
   return SPAM_DISPATCH_DTYPE(a->dtype, spmv_prepare_t<double>(a, d_x, s), spmv_prepare_t<float>(a, d_x, s),
                              spmv_prepare_t<i64w>(a, d_x, s));
 }
@@ -1968,6 +1970,7 @@ int spam_csr_values_changed(spam_csr* a) {
   std::lock_guard<std::mutex> lk(a->plan_mu);
   SpmvPlan* p = a->spmv_plan;
   if (!p || !p->sliced) return SPAM_OK;  // the plain path reads the values where they are
+  SPAM_TRY(wait_values(a, stream()));
   return SPAM_DISPATCH_DTYPE(a->dtype, sliced_refresh_values<double>(a, p->sliced, stream()),
                              sliced_refresh_values<float>(a, p->sliced, stream()),
                              sliced_refresh_values<i64w>(a, p->sliced, stream()));

@@ -24,6 +24,8 @@ Everything here works on torch tensors of any device, so the logic is exercised 
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 
@@ -189,3 +191,85 @@ def allgather_vector(x_local: torch.Tensor, n: int, rank: int, world: int, dist=
     for r, (lo, hi) in enumerate(blocks):
         x[lo:hi] = out[r * maxb: r * maxb + (hi - lo)]
     return x
+
+
+class RcclComm:
+    """The exchange behind the C ABI (include/spam_hip_rccl.h, libspam_hip_rccl.so): what a Rust host calls.  This class
+    only moves pointers; the communicator, the exchange stream, the grouped ncclSend / ncclRecv, the row_ptr fix-up and the
+    event that holds back readers of the values all live in the library.  torch.distributed (any backend) is used for
+    ONE thing here: handing rank 0's 128-byte unique id to the other ranks."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        from . import _lib
+
+        _lib.ensure_device()
+        self._L = _lib.load_rccl()
+        self._check = _lib.check
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), _lib.RCCL_ID_BYTES)
+        _lib.check(self._L.spam_rccl_comm_create(buf, rank, world, C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _lib
+
+        buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+        _lib.check(_lib.load_rccl().spam_rccl_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_dist(cls, dist, rank: int, world: int) -> "RcclComm":
+        """Rank 0 draws the id; the process group (gloo or nccl) broadcasts its 128 bytes."""
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        return cls(rank, world, box[0])
+
+    def allgather_csr(self, shard, row_offsets):
+        """shard: DeviceCsr of this rank's rows; returns the gathered DeviceCsr (values possibly still in flight: only
+        kernels that read them wait) and the bytes this rank received."""
+        from .csr import DeviceCsr
+
+        offs = (C.c_uint64 * (self.world + 1))(*[int(v) for v in row_offsets])
+        h = C.c_void_p()
+        self._check(self._L.spam_csr_allgather_rccl(self._h, shard._h, offs, C.byref(h)))
+        return DeviceCsr(h), self.last_exchange()[0]
+
+    def allgather_vector(self, x_local: torch.Tensor, counts) -> torch.Tensor:
+        cnt = (C.c_uint64 * self.world)(*[int(v) for v in counts])
+        out = torch.empty(int(sum(counts)), dtype=x_local.dtype, device=x_local.device)
+        self._check(self._L.spam_vector_allgather_rccl(self._h, x_local.element_size(), C.c_void_p(x_local.data_ptr()), cnt,
+                                                       C.c_void_p(out.data_ptr())))
+        return out
+
+    def rank_step(self, a_full, b_full, count_offsets=None, row_overhead: int = ROW_OVERHEAD_PRODUCTS, sort_rows=False):
+        """spam_spgemm_rank_step_rccl: sharded flop count + all-gather of the counts + partition + this rank's block of
+        C.  Returns (C block or None, stats dict, (row_lo, row_hi))."""
+        from ._lib import SpgemmStats
+        from .csr import DeviceCsr
+
+        co = (C.c_uint64 * (self.world + 1))(*[int(v) for v in count_offsets]) if count_offsets is not None else None
+        h = C.c_void_p()
+        st = SpgemmStats()
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._check(self._L.spam_spgemm_rank_step_rccl(self._h, a_full._h, b_full._h, co, row_overhead, int(sort_rows),
+                                                       C.byref(h), C.byref(lo), C.byref(hi), C.byref(st)))
+        return (DeviceCsr(h) if h.value else None), st.asdict(), (lo.value, hi.value)
+
+    def last_exchange(self):
+        r, s = C.c_uint64(), C.c_uint64()
+        self._check(self._L.spam_rccl_last_exchange(self._h, C.byref(r), C.byref(s)))
+        return r.value, s.value
+
+    def free(self):
+        if self._h:
+            self._L.spam_rccl_comm_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

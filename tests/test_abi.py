@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "spam_hip.h")).read()
+def declared_symbols(header="spam_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(spam_[a-z0-9_]+)\s*\(", text)))
 
@@ -24,7 +24,22 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in spam_hip.h but missing from libspam_hip.so"
     assert sorted(_lib.SYMBOLS) == names, "python binding table and header disagree"
-    assert lib.spam_version() == 1001
+    assert lib.spam_version() == 1002
+
+
+def test_rccl_sibling_exports_its_header():
+    """libspam_hip_rccl.so (the multi-GPU exchange, include/spam_hip_rccl.h) loads next to libspam_hip.so, links RCCL
+    and exports / binds exactly what its header declares.  No communicator is created without a GPU."""
+    from sparse_matrix_amd import _lib
+
+    lib = _lib.load_rccl()
+    names = declared_symbols("spam_hip_rccl.h")
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in spam_hip_rccl.h but missing from libspam_hip_rccl.so"
+    assert sorted(_lib.SYMBOLS_RCCL) == names, "python binding table and header disagree"
+    out = os.popen(f"readelf -d {_lib.LIB_RCCL_PATH}").read()
+    assert "librccl.so" in out and "libspam_hip.so" in out
+    assert "librccl" not in os.popen(f"readelf -d {_lib.LIB_PATH}").read(), "single-GPU hosts must not need RCCL"
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

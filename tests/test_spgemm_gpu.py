@@ -18,7 +18,7 @@ from helpers import assert_csr_parity, csr_np, rows_as_sets
 pytestmark = pytest.mark.gpu
 
 F64_RTOL = 1e-10
-F32_RTOL = 2e-5
+F32_RTOL = 1e-5
 
 
 def _mk(spam, m, is_sorted=True):
@@ -527,3 +527,38 @@ def test_randomized_shapes_all_orders(spam, oracle):
         assert_csr_parity((Ct.offsets, Ct.indices, Ct.vals), wu, False, rtol)
         Cr = A.mul_hash(B, reference_order=True)
         assert np.array_equal(Cr.offsets, wu[0]) and np.array_equal(Cr.indices, wu[1]), f"case {case}"
+
+
+@pytest.mark.parametrize("n_out", [3, 40, 300, 1500, 3000, 6000])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_first_product_is_stored_not_added_to_zero(spam, oracle, n_out, dtype):
+    """`or_insert(t1)` STORES the first product of a column (/root/reference/spam_csr/src/mul_hash.rs:157-161,
+    /root/reference/linprobe/src/map.rs:113-116) — so a product that underflows to -0.0 comes out as -0.0, and
+    (-0.0) + (-0.0) stays -0.0, while one +0.0 among them gives +0.0.  An accumulator that starts at +0.0 would flip
+    those signs; the kernels start theirs at -0.0.  Known answer, hand-derived, one row per numeric bin (16-lane and
+    64-lane hash tables, the two one-row-per-workgroup tables, the rank-addressed heavy path beyond 4096 entries):
+    row 0 of A = [t, t] against two rows of B of n_out entries each with t*b underflowing: columns where both
+    products are -0.0 keep the sign bit, columns where the second is +0.0 lose it."""
+    tiny = dtype(1e-200) if dtype == np.float64 else dtype(1e-30)
+    a_vals = np.array([-tiny, tiny], dtype=dtype)              # A = 1 x 2
+    A = spam.CsrMatrix(1, 2, a_vals, np.array([0, 1], dtype=np.uint64), np.array([0, 2], dtype=np.uint64), True)
+    cols = np.arange(n_out, dtype=np.uint64)
+    b0 = np.full(n_out, tiny, dtype=dtype)                     # (-tiny) * tiny      -> -0.0 (first product of every column)
+    b1 = np.where(cols % 2 == 0, -tiny, tiny).astype(dtype)    # tiny * (-/+ tiny)   -> -0.0 on even, +0.0 on odd columns
+    B = spam.CsrMatrix(2, n_out, np.concatenate([b0, b1]), np.concatenate([cols, cols]),
+                       np.array([0, n_out, 2 * n_out], dtype=np.uint64), True)
+    want_sign = (cols % 2 == 0)                                # -0.0 + -0.0 = -0.0 ; -0.0 + +0.0 = +0.0
+    host_a = (A.offsets, A.indices, A.vals)
+    host_b = (B.offsets, B.indices, B.vals)
+    for sort_rows in (True, False):
+        C = A.mul_hash(B, sort_output=sort_rows)
+        wo, wi, wv = oracle.mul_hash(host_a, host_b, sort_rows=sort_rows)
+        assert C.nnz() == n_out and np.all(C.vals == 0), "cancellation / underflow keeps explicit zeros"
+        order = np.argsort(C.indices, kind="stable")
+        assert np.array_equal(np.signbit(C.vals[order]), want_sign), "sign of zero (hand-derived)"
+        assert np.array_equal(np.signbit(wv[np.argsort(wi, kind='stable')]), want_sign), "the oracle agrees with the hand derivation"
+    # a single product of -0.0 per column: the first (and only) product is what the reference stores
+    A1 = spam.CsrMatrix(1, 1, np.array([-tiny], dtype=dtype), np.array([0], dtype=np.uint64), np.array([0, 1], dtype=np.uint64), True)
+    B1 = spam.CsrMatrix(1, n_out, b0, cols, np.array([0, n_out], dtype=np.uint64), True)
+    C1 = A1.mul_hash(B1, sort_output=True)
+    assert np.all(C1.vals == 0) and np.all(np.signbit(C1.vals)), "a lone -0.0 product must stay -0.0"

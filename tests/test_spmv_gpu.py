@@ -243,7 +243,7 @@ def test_randomized_shapes(spam, oracle):
         ref = oracle.spmv((off, idx.astype(np.uint64), val.astype(np.float64)), x.astype(np.float64))
         nz = ref != 0
         assert np.all(y[~nz] == 0), f"case {case}"
-        rtol = F64_RTOL if dtype == np.float64 else 3e-5
+        rtol = F64_RTOL if dtype == np.float64 else F32_RTOL
         if nz.any():
             assert (np.abs(y[nz].astype(np.float64) - ref[nz]) / np.abs(ref[nz])).max() <= rtol, f"case {case}"
 

@@ -18,7 +18,7 @@ from helpers import csr_np
 pytestmark = pytest.mark.gpu
 
 F64_RTOL = 1e-10
-F32_RTOL = 3e-5
+F32_RTOL = 1e-5
 
 ENV_KEYS = ("SPAM_SPMV_SLICED", "SPAM_SPMV_SLICE_KB", "SPAM_SPMV_LDS_KB", "SPAM_SPMV_LONG", "SPAM_SPMV_SLICED_TPB",
             "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS", "SPAM_SPMV_L0_KB", "SPAM_SPMV_PIPE", "SPAM_SPMV_RG",
