@@ -178,6 +178,7 @@ struct RgKnobs {
   int fold_short = 1; // SPAM_SPMV_RG_SHORT  the short rows as blocks of the same kernel (0: spmv_short_rows_kernel)
   int prof = 0;       // SPAM_SPMV_PROF = 3   per-block phase timers, printed by every SpMV (diagnostics)
   int order_min = 32; // SPAM_SPMV_RG_ORDER  rows with fewer entries are ranked in row order (coalesced y writes), longer ones by length
+  int fmt = 2;        // SPAM_SPMV_RG_FMT    packed entry words a block may use: 0 none (32-bit words), 1 up to 24-bit, 2 up to 16-bit
 };
 struct RgPlan {
   uint32_t ng = 0, abits = 0, lds_bytes = 0, nl = 0, ntiles = 0;

@@ -736,6 +736,7 @@ static SpmvKnobs read_knobs() {
   k.rgk.acc_bits = env_int("SPAM_SPMV_RG_ABITS", 0);
   k.rgk.fold_short = env_int("SPAM_SPMV_RG_SHORT", 1);
   k.rgk.order_min = env_int("SPAM_SPMV_RG_ORDER", k.rgk.order_min);
+  k.rgk.fmt = env_int("SPAM_SPMV_RG_FMT", k.rgk.fmt);
   k.rgk.prof = k.prof;
 
   return k;

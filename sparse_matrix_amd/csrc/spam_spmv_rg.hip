@@ -68,6 +68,47 @@ template <class T>
 __host__ __device__ constexpr uint32_t rg_chunk_bytes(bool wide) {
   return 1024u + (wide ? 512u : 0u) + 256u * (uint32_t)sizeof(T);
 }
+// PACKED chunk formats of the slab parts (round 4).  A block's entries are sorted by table slot, so inside a chunk the
+// slot of sorted entry e is the slot of entry e - 1 plus a small DELTA (a 200 k-entry block walks a 347 k-slot table:
+// 1.7 slots per entry); the entry word then needs the 13 accumulator bits and a few delta bits instead of a 19-bit slot:
+//   fmt 0: 32-bit words, slot << abits | accumulator (the plain format above), 12 bytes per f64 entry;
+//   fmt 1: 24-bit words, delta (11 bits) << 13 | accumulator, 11 bytes per f64 entry;
+//   fmt 2: 16-bit words, delta (3 bits) << 13 | accumulator, 10 bytes per f64 entry (6 per f32 entry instead of 8).
+// A packed chunk starts with a 16-byte header (word 0: the absolute slot of its first entry, whose own delta field is
+// 0); lane l's four words are bytes [HDR + 4 b l, HDR + 4 b (l + 1)) (b = 2 or 3 bytes per word), its k-th word sorted
+// entry 64 k + l as before, so a gather instruction still covers 64 consecutive sorted entries.  A delta that does not
+// fit is bridged by PADDING entries (spare accumulator, value 0, delta 7 / 2047); rg_build picks per block the format
+// with the fewest bytes (sparse blocks keep fmt 0).  The slots are rebuilt by four wave prefix sums per chunk (DPP).
+constexpr uint32_t RG_FMT_SHIFT = 30, RG_NCHUNK_MASK = (1u << RG_FMT_SHIFT) - 1u;  // RgBlk::nchunks carries the format
+constexpr uint32_t RG_PK_HDR = 16, RG_PK_ACC_BITS = 13, RG_PK_ACC_MASK = (1u << RG_PK_ACC_BITS) - 1u;
+__host__ __device__ constexpr uint32_t rg_fmt_word_bytes(uint32_t fmt) { return fmt == 2 ? 2u : fmt == 1 ? 3u : 4u; }
+__host__ __device__ constexpr uint32_t rg_fmt_max_delta(uint32_t fmt) { return fmt == 2 ? 7u : 2047u; }
+// byte offset of the value array inside a chunk / size of a chunk, by format (wide: the cold part and the short rows)
+template <class T>
+__host__ __device__ constexpr uint32_t rg_fmt_voff(bool wide, uint32_t fmt) {
+  return wide ? 1536u : fmt == 0 ? 1024u : RG_PK_HDR + 256u * rg_fmt_word_bytes(fmt);
+}
+template <class T>
+__host__ __device__ constexpr uint32_t rg_fmt_chunk_bytes(bool wide, uint32_t fmt) {
+  return rg_fmt_voff<T>(wide, fmt) + 256u * (uint32_t)sizeof(T);
+}
+// inclusive prefix sum over the 64 lanes (DPP: Hillis-Steele inside the 16-lane rows, then the two row broadcasts)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t rg_dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t rg_wave_incl_scan(uint32_t v) {
+  v += rg_dpp_u32<0x111, 0xF>(v);  // row_shr:1
+  v += rg_dpp_u32<0x112, 0xF>(v);  // row_shr:2
+  v += rg_dpp_u32<0x114, 0xF>(v);  // row_shr:4
+  v += rg_dpp_u32<0x118, 0xF>(v);  // row_shr:8
+  v += rg_dpp_u32<0x142, 0xA>(v);  // row_bcast:15 -> rows 1 and 3
+  v += rg_dpp_u32<0x143, 0xC>(v);  // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+struct __attribute__((packed, aligned(4))) RgU3 {
+  uint32_t x, y, z;
+};
 // position of the k-th entry of lane `lane` inside a chunk's value array
 template <class T>
 __host__ __device__ __forceinline__ uint32_t rg_val_slot(uint32_t lane, uint32_t k) {
@@ -200,6 +241,74 @@ __device__ __forceinline__ void rg_stream(const unsigned char* p0, uint32_t nchu
   }
 }
 
+// The same for a block in a packed format (WB = 2 or 3 bytes per entry word): the slots of a chunk are its header's
+// base plus the running sum of the delta fields in sorted order (entry 64 k + l = word k of lane l): one wave prefix sum
+// per k, the total of each carried into the next.
+template <class T, int NT, int K, int WB>
+__device__ __forceinline__ void rg_stream_packed(const unsigned char* p0, uint32_t nchunks, int wave, int lane,
+                                                 const T RG_GLB* xg, typename RgAcc<T>::type* acc) {
+  typedef RgAcc<T> A;
+  constexpr int nw = NT / 64;
+  constexpr uint32_t VOFF = RG_PK_HDR + 256u * (uint32_t)WB, CB = VOFF + 256u * (uint32_t)sizeof(T);
+  auto load_words = [&](const unsigned char* q, uint32_t (&e)[4]) {
+    if constexpr (WB == 2) {
+      const u32x2 w = __builtin_nontemporal_load((const u32x2*)(q + RG_PK_HDR + 8 * lane));
+      e[0] = w.x & 0xFFFFu, e[1] = w.x >> 16, e[2] = w.y & 0xFFFFu, e[3] = w.y >> 16;
+    } else {
+      const uint32_t* wp = (const uint32_t*)(q + RG_PK_HDR + 12 * lane);  // (three 4-byte nt loads: merged into one dwordx3)
+      RgU3 w;
+      w.x = __builtin_nontemporal_load(wp), w.y = __builtin_nontemporal_load(wp + 1), w.z = __builtin_nontemporal_load(wp + 2);
+      e[0] = w.x & 0xFFFFFFu, e[1] = (w.x >> 24) | ((w.y & 0xFFFFu) << 8), e[2] = (w.y >> 16) | ((w.z & 0xFFu) << 16), e[3] = w.z >> 8;
+    }
+  };
+  auto slots_of = [&](uint32_t base, const uint32_t (&e)[4], uint32_t (&sl)[4]) {
+    uint32_t run = base;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t inc = rg_wave_incl_scan(e[j] >> RG_PK_ACC_BITS);
+      sl[j] = run + inc;
+      run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+  };
+  uint32_t c = (uint32_t)wave;
+  for (; c + (uint32_t)(K - 1) * nw < nchunks; c += (uint32_t)K * nw) {
+    uint32_t e[K][4], base[K], sl[K][4];
+    T v[K][4], xv[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const unsigned char* q = p0 + (uint64_t)(c + (uint32_t)k * nw) * CB;
+      base[k] = *(const uint32_t*)q;  // (uniform address)
+      load_words(q, e[k]);
+      rg_load_vals<T>(q + VOFF, lane, v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) slots_of(base[k], e[k], sl[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      xv[k][0] = xg[sl[k][0]], xv[k][1] = xg[sl[k][1]], xv[k][2] = xg[sl[k][2]], xv[k][3] = xg[sl[k][3]];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(&acc[e[k][j] & RG_PK_ACC_MASK], A::prod(v[k][j], xv[k][j]));
+    }
+  }
+  for (; c < nchunks; c += nw) {
+    const unsigned char* q = p0 + (uint64_t)c * CB;
+    uint32_t e[4], sl[4];
+    T v[4];
+    const uint32_t base = *(const uint32_t*)q;
+    load_words(q, e);
+    rg_load_vals<T>(q + VOFF, lane, v);
+    slots_of(base, e, sl);
+    const T x0 = xg[sl[0]], x1 = xg[sl[1]], x2 = xg[sl[2]], x3 = xg[sl[3]];
+    atomicAdd(&acc[e[0] & RG_PK_ACC_MASK], A::prod(v[0], x0));
+    atomicAdd(&acc[e[1] & RG_PK_ACC_MASK], A::prod(v[1], x1));
+    atomicAdd(&acc[e[2] & RG_PK_ACC_MASK], A::prod(v[2], x2));
+    atomicAdd(&acc[e[3] & RG_PK_ACC_MASK], A::prod(v[3], x3));
+  }
+}
+
 // Persistent workgroups.  A workgroup reads the XCD it runs on and serves that slab's queue, then the cold queue, the
 // short rows, then whatever the other slabs have left (so nothing depends on the placement); one workgroup in four
 // starts with the cold queue and the short rows, whose blocks wait for fabric round trips and overlap with the
@@ -230,7 +339,7 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
       continue;
     }
     const RgBlk* bd = P.blk + (P.qbase[part] + g);
-    const uint32_t nchunks = bd->nchunks;
+    const uint32_t nchunks = bd->nchunks & RG_NCHUNK_MASK, fmt = bd->nchunks >> RG_FMT_SHIFT;
     if (nchunks == 0) continue;  // no entry of this group in this part (its pairs, if any, stay zero)
     const uint64_t off = bd->off, cp0 = bd->cp0;
     const uint32_t nheads = bd->nheads, nsubs = bd->nsubs & ~RG_PIECE, sub0 = bd->sub0;
@@ -243,6 +352,10 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
     if (P.times) t1 = wall_clock64();
     if (part >= (uint32_t)SPMV_NSLAB)
       rg_stream<T, NT, K, true>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[SPMV_NSLAB], acc, P.abits);
+    else if (fmt == 2)  // (uniform: a block has one format)
+      rg_stream_packed<T, NT, K, 2>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc);
+    else if (fmt == 1)
+      rg_stream_packed<T, NT, K, 3>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc);
     else
       rg_stream<T, NT, K, false>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc, P.abits);
     __syncthreads();
@@ -430,44 +543,126 @@ __device__ __forceinline__ uint32_t rg_find_block(const uint64_t* __restrict__ p
   return lo;
 }
 
-// One thread per padded entry position (in sorted order inside its chunk): write the entry word, accumulator and
-// value at the position the kernel's lanes read them from, and remember where the value came from.
+__device__ __forceinline__ uint32_t rg_key_slot(uint64_t key) { return (uint32_t)(key >> RG_KEY_ACC_BITS); }  // (low 32 bits of the shifted key)
+// padding entries a packed format with deltas up to `maxd` needs in front of an entry that lies d slots after its predecessor
+__device__ __forceinline__ uint32_t rg_pads(uint32_t d, uint32_t maxd) { return d ? (d - 1u) / maxd : 0u; }
+
+// Per block of the slab parts: the padding entries the 16-bit and the 24-bit format would need (sum over its entries).
+__global__ void rg_padsum_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint32_t first_wide,
+                                 unsigned long long* __restrict__ sum16, unsigned long long* __restrict__ sum24) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t p16 = 0, p24 = 0;
+  uint64_t b = ~0ull;
+  if (j < n) {
+    const uint64_t k = keys[j];
+    b = k >> RG_KEY_BLK_SHIFT;
+    if (b < first_wide && j > 0) {
+      const uint64_t kp = keys[j - 1];
+      if ((kp >> RG_KEY_BLK_SHIFT) == b) {
+        const uint32_t d = rg_key_slot(k) - rg_key_slot(kp);
+        p16 = rg_pads(d, rg_fmt_max_delta(2)), p24 = rg_pads(d, rg_fmt_max_delta(1));
+      }
+    }
+  }
+  // entries are sorted by block: a wavefront usually lies inside one
+  const uint64_t b0 = __shfl(b, 0, 64);
+  if (__ballot(b != b0) == 0ull) {
+    uint32_t s16 = p16, s24 = p24;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s16 += __shfl_xor(s16, o, 64), s24 += __shfl_xor(s24, o, 64);
+    if ((threadIdx.x & 63) == 0 && b0 != ~0ull && b0 < first_wide) {
+      if (s16) atomicAdd(&sum16[b0], (unsigned long long)s16);
+      if (s24) atomicAdd(&sum24[b0], (unsigned long long)s24);
+    }
+  } else if (b != ~0ull && b < first_wide) {
+    if (p16) atomicAdd(&sum16[b], (unsigned long long)p16);
+    if (p24) atomicAdd(&sum24[b], (unsigned long long)p24);
+  }
+}
+// The padding in front of every entry under its block's chosen format (0 for fmt 0 and the wide blocks).
+__global__ void rg_padsel_kernel(const uint64_t* __restrict__ keys, uint64_t n, const RgBlk* __restrict__ blk,
+                                 uint32_t* __restrict__ pad) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint64_t k = keys[j], b = k >> RG_KEY_BLK_SHIFT;
+  const uint32_t fmt = blk[b].nchunks >> RG_FMT_SHIFT;
+  uint32_t m = 0;
+  if (fmt && j > 0) {
+    const uint64_t kp = keys[j - 1];
+    if ((kp >> RG_KEY_BLK_SHIFT) == b) m = rg_pads(rg_key_slot(k) - rg_key_slot(kp), rg_fmt_max_delta(fmt));
+  }
+  pad[j] = m;
+}
+
+// One thread per entry (in sorted order): write its word and value at the position the kernel's lanes read them from
+// (sorted position inside the block, padding included, -> chunk, k, lane), the padding entries a packed format needs in
+// front of it, and — the block's last entry — the padding that fills the block's last chunk.  The stream is zero and vsrc
+// RG_NONE before: padding values and sources need no store.
 // (first_wide = 8 * ng: the cold part and the short-row blocks use the wide chunk format; first_short = 9 * ng.)
 template <class T>
 __global__ void rg_fill_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ src_sorted,
                                const uint64_t* __restrict__ start, const uint64_t* __restrict__ pe,
-                               const RgBlk* __restrict__ blk, uint32_t nb, uint32_t first_wide, uint32_t first_short,
+                               const uint64_t* __restrict__ pad_before /* exclusive prefix of pad, n + 1; null: no packed block */,
+                               const RgBlk* __restrict__ blk, uint32_t first_wide, uint32_t first_short,
                                uint32_t abits, const T* __restrict__ vals, const T* __restrict__ short_vals,
-                               unsigned char* __restrict__ stream, uint32_t* __restrict__ vsrc, uint64_t padded) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= padded) return;
-  const uint32_t b = rg_find_block(pe, nb, q);
+                               unsigned char* __restrict__ stream, uint32_t* __restrict__ vsrc, uint64_t n) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint64_t key = keys[j];
+  const uint32_t b = (uint32_t)(key >> RG_KEY_BLK_SHIFT);
+  const uint32_t idx = rg_key_slot(key), a = (uint32_t)(key & ((1u << RG_KEY_ACC_BITS) - 1u));
   const bool is_short = b >= first_short, wide = b >= first_wide;
   const RgBlk bd = blk[b];
-  const uint64_t jb = q - pe[b];
-  const uint64_t chunk = jb >> 8;
-  const uint32_t w = (uint32_t)(jb & 255u), lane = w & 63u, k = w >> 6;
-  const uint64_t cnt = start[b + 1] - start[b];
-  uint32_t idx = 0, a = bd.nheads + bd.nsubs, p = RG_NONE;  // padding: the block's spare accumulator
-  T v = T(0);
-  if (jb < cnt) {
-    const uint64_t key = keys[start[b] + jb];
-    idx = (uint32_t)(key >> RG_KEY_ACC_BITS);
-    a = (uint32_t)(key & ((1u << RG_KEY_ACC_BITS) - 1u));
-    p = src_sorted[start[b] + jb];
-    v = is_short ? short_vals[p] : vals[p];
+  const uint32_t nch = bd.nchunks & RG_NCHUNK_MASK, fmt = wide ? 0u : bd.nchunks >> RG_FMT_SHIFT;
+  const uint32_t spare = bd.nheads + bd.nsubs;  // the block's spare accumulator takes the padding
+  const uint64_t sb = start[b], last = start[b + 1] - 1;
+  const uint32_t cb = wide ? rg_chunk_bytes<T>(true) : fmt == 2 ? rg_fmt_chunk_bytes<T>(false, 2)
+                      : fmt == 1 ? rg_fmt_chunk_bytes<T>(false, 1) : rg_chunk_bytes<T>(false);
+  const uint32_t voff = wide ? 1536u : fmt == 2 ? rg_fmt_voff<T>(false, 2) : fmt == 1 ? rg_fmt_voff<T>(false, 1) : 1024u;
+  const uint32_t wb = rg_fmt_word_bytes(fmt);
+  auto put = [&](uint64_t pos, uint32_t slot, uint32_t delta, uint32_t acc, bool real, uint32_t src, T v) {
+    const uint64_t chunk = pos >> 8;
+    const uint32_t w = (uint32_t)(pos & 255u), lane = w & 63u, k = w >> 6;
+    unsigned char* c = stream + bd.off + chunk * cb;
+    const uint32_t wpos = 4u * lane + k;
+    if (wide) {
+      reinterpret_cast<uint32_t*>(c)[wpos] = slot;
+      reinterpret_cast<uint16_t*>(c + 1024)[wpos] = (uint16_t)acc;
+    } else if (fmt == 0) {
+      reinterpret_cast<uint32_t*>(c)[wpos] = (slot << abits) | acc;
+    } else {
+      if (w == 0) {  // the chunk's first entry: absolute slot in the header, no delta
+        *reinterpret_cast<uint32_t*>(c) = slot;
+        delta = 0;
+      }
+      const uint32_t word = (delta << RG_PK_ACC_BITS) | acc;
+      unsigned char* d = c + RG_PK_HDR + wb * wpos;
+      if (fmt == 2) {
+        *reinterpret_cast<uint16_t*>(d) = (uint16_t)word;
+      } else {
+        d[0] = (unsigned char)word, d[1] = (unsigned char)(word >> 8), d[2] = (unsigned char)(word >> 16);
+      }
+    }
+    if (real) {
+      const uint32_t vs = rg_val_slot<T>(lane, k);
+      reinterpret_cast<T*>(c + voff)[vs] = v;
+      vsrc[pe[b] + (chunk << 8) + vs] = src;
+    }
+  };
+  uint64_t pos = j - sb;
+  uint32_t delta = 0;
+  if (fmt) {
+    const uint32_t m = (uint32_t)(pad_before[j + 1] - pad_before[j]);
+    pos += pad_before[j + 1] - pad_before[sb];  // (the block's first entry has no padding in front of it)
+    if (j > sb) {
+      const uint32_t maxd = rg_fmt_max_delta(fmt), prev = rg_key_slot(keys[j - 1]);
+      for (uint32_t i = 0; i < m; ++i) put(pos - m + i, prev + maxd * (i + 1u), maxd, spare, false, RG_NONE, T(0));
+      delta = idx - (prev + maxd * m);
+    }
   }
-  unsigned char* c = stream + bd.off + chunk * (wide ? rg_chunk_bytes<T>(true) : rg_chunk_bytes<T>(false));
-  const uint32_t wpos = 4u * lane + k;
-  if (wide) {
-    reinterpret_cast<uint32_t*>(c)[wpos] = idx;
-    reinterpret_cast<uint16_t*>(c + 1024)[wpos] = (uint16_t)a;
-  } else {
-    reinterpret_cast<uint32_t*>(c)[wpos] = (idx << abits) | a;
-  }
-  const uint32_t vs = rg_val_slot<T>(lane, k);
-  reinterpret_cast<T*>(c + (wide ? 1536 : 1024))[vs] = v;
-  vsrc[pe[b] + (chunk << 8) + vs] = p;
+  put(pos, idx, delta, a, true, src_sorted[j], is_short ? short_vals[src_sorted[j]] : vals[src_sorted[j]]);
+  if (j == last)
+    for (uint64_t q = pos + 1; q < (uint64_t)nch * 256u; ++q) put(q, idx, 0u, spare, false, RG_NONE, T(0));
 }
 
 // spam_csr_values_changed: one thread per padded value position
@@ -482,9 +677,12 @@ __global__ void rg_refresh_kernel(const uint64_t* __restrict__ pe, const RgBlk* 
   if (p == RG_NONE) return;
   const uint32_t b = rg_find_block(pe, nb, q);
   const bool is_short = b >= first_short, wide = b >= first_wide;
+  const uint32_t fmt = wide ? 0u : blk[b].nchunks >> RG_FMT_SHIFT;
+  const uint32_t cb = fmt == 2 ? rg_fmt_chunk_bytes<T>(false, 2) : fmt == 1 ? rg_fmt_chunk_bytes<T>(false, 1) : rg_chunk_bytes<T>(wide);
+  const uint32_t voff = fmt == 2 ? rg_fmt_voff<T>(false, 2) : fmt == 1 ? rg_fmt_voff<T>(false, 1) : (wide ? 1536u : 1024u);
   const uint64_t jb = q - pe[b];
-  unsigned char* c = stream + blk[b].off + (jb >> 8) * (wide ? rg_chunk_bytes<T>(true) : rg_chunk_bytes<T>(false));
-  reinterpret_cast<T*>(c + (wide ? 1536 : 1024))[jb & 255u] = is_short ? short_vals[p] : vals[p];
+  unsigned char* c = stream + blk[b].off + (jb >> 8) * cb;
+  reinterpret_cast<T*>(c + voff)[jb & 255u] = is_short ? short_vals[p] : vals[p];
 }
 
 static int bits_for(uint64_t v) {  // bits needed to represent values 0..v
@@ -833,20 +1031,56 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   rg_bounds_kernel<<<(unsigned)((n_all + 255) / 256), 256, 0, s>>>(keys_out.as<uint64_t>(), n_all, start.as<uint64_t>());
   SPAM_CHECK_LAUNCH();
   std::vector<uint64_t> h_start((size_t)nb + 1), h_pe((size_t)nb + 1);
+  // the packed formats: padding each would need, per block of the slab parts
+  const int fmt_max = abits <= (int)RG_PK_ACC_BITS ? std::max(0, std::min(2, kn.fmt)) : 0;
+  DevBuf sum16, sum24;
+  std::vector<unsigned long long> h16((size_t)first_wide + 1, 0ull), h24((size_t)first_wide + 1, 0ull);
+  if (fmt_max > 0) {
+    SPAM_TRY(sum16.alloc(((uint64_t)first_wide + 1) * 8));
+    SPAM_TRY(sum24.alloc(((uint64_t)first_wide + 1) * 8));
+    SPAM_HIP_TRY(hipMemsetAsync(sum16.p, 0, ((uint64_t)first_wide + 1) * 8, s));
+    SPAM_HIP_TRY(hipMemsetAsync(sum24.p, 0, ((uint64_t)first_wide + 1) * 8, s));
+    rg_padsum_kernel<<<(unsigned)((n_all + 255) / 256), 256, 0, s>>>(keys_out.as<uint64_t>(), n_all, first_wide,
+                                                                     sum16.as<unsigned long long>(), sum24.as<unsigned long long>());
+    SPAM_CHECK_LAUNCH();
+    SPAM_HIP_TRY(hipMemcpyAsync(h16.data(), sum16.p, (uint64_t)first_wide * 8, hipMemcpyDeviceToHost, s));
+    SPAM_HIP_TRY(hipMemcpyAsync(h24.data(), sum24.p, (uint64_t)first_wide * 8, hipMemcpyDeviceToHost, s));
+  }
   SPAM_HIP_TRY(hipMemcpyAsync(h_start.data(), start.p, ((uint64_t)nb + 1) * 8, hipMemcpyDeviceToHost, s));
   SPAM_HIP_TRY(hipStreamSynchronize(s));
   h_start[nb] = n_all;
   for (uint32_t b = nb; b-- > 0;)
     if (h_start[b] == ~0ull) h_start[b] = h_start[b + 1];
   h_pe[0] = 0;
-  uint64_t off = 0, nonempty = 0;
+  uint64_t off = 0, nonempty = 0, fmt_entries[3] = {0, 0, 0}, fmt_pads = 0;
+  bool any_packed = false;
   for (uint32_t b = 0; b < nb; ++b) {
-    const uint64_t cnt = h_start[b + 1] - h_start[b], nch = (cnt + 255) / 256;
-    h_blk[b].off = off, h_blk[b].nchunks = (uint32_t)nch;
-    off += nch * rg_chunk_bytes<T>(b >= first_wide);
+    const uint64_t cnt = h_start[b + 1] - h_start[b];
+    const bool wide = b >= first_wide;
+    // the format with the fewest bytes (the plain one for the cold part, the short rows and sparse blocks)
+    uint32_t fmt = 0;
+    uint64_t nel = cnt, bytes = ((cnt + 255) / 256) * rg_chunk_bytes<T>(wide);
+    if (!wide && cnt > 0 && fmt_max > 0) {
+      const uint64_t n24 = cnt + h24[b], b24 = ((n24 + 255) / 256) * rg_fmt_chunk_bytes<T>(false, 1);
+      if (b24 < bytes && n24 < (1ull << 38)) fmt = 1, nel = n24, bytes = b24;
+      if (fmt_max > 1) {
+        const uint64_t n16 = cnt + h16[b], b16 = ((n16 + 255) / 256) * rg_fmt_chunk_bytes<T>(false, 2);
+        if (b16 < bytes && n16 < (1ull << 38)) fmt = 2, nel = n16, bytes = b16;
+      }
+    }
+    const uint64_t nch = (nel + 255) / 256;
+    if (nch > RG_NCHUNK_MASK) return SPAM_OK;  // (a block of 2^38 entries: the caller keeps the tile form)
+    h_blk[b].off = off, h_blk[b].nchunks = (uint32_t)nch | (fmt << RG_FMT_SHIFT);
+    off += bytes;
     h_pe[b + 1] = h_pe[b] + nch * 256;
     nonempty += cnt != 0;
+    fmt_entries[fmt] += cnt, fmt_pads += nel - cnt;
+    any_packed |= fmt != 0;
   }
+  if (kn.prof == 4)
+    fprintf(stderr, "[spam] prepare:     rg: entry words 32 / 24 / 16 bit: %llu / %llu / %llu entries, %llu padding entries, stream %.3f GB\n",
+            (unsigned long long)fmt_entries[0], (unsigned long long)fmt_entries[1], (unsigned long long)fmt_entries[2],
+            (unsigned long long)fmt_pads, (double)off / 1e9);
   h_blk[nb].off = off;
   g->stream_bytes = off, g->padded = h_pe[nb];
   // the kernel's queues: the blocks part by part, a block of few rows and many entries as pieces (RG_PIECE)
@@ -860,12 +1094,13 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
       const uint32_t cnt = part < (uint32_t)SPMV_NPART ? ng : ngs;
       for (uint32_t i = 0; i < cnt; ++i) {
         const RgBlk d = h_blk[(size_t)part * ng + i];
-        if (part < (uint32_t)SPMV_NPART && d.nheads > 0 && d.nheads <= RG_PIECE_MAX_HEADS && d.nchunks > 2 * piece_chunks) {
-          const uint32_t m = (d.nchunks + piece_chunks - 1) / piece_chunks, per = (d.nchunks + m - 1) / m;
-          const uint64_t cb = rg_chunk_bytes<T>(part >= (uint32_t)SPMV_NSLAB);
-          for (uint32_t c0 = 0; c0 < d.nchunks; c0 += per) {
+        const uint32_t d_nch = d.nchunks & RG_NCHUNK_MASK, d_fmt = d.nchunks >> RG_FMT_SHIFT;
+        if (part < (uint32_t)SPMV_NPART && d.nheads > 0 && d.nheads <= RG_PIECE_MAX_HEADS && d_nch > 2 * piece_chunks) {
+          const uint32_t m = (d_nch + piece_chunks - 1) / piece_chunks, per = (d_nch + m - 1) / m;
+          const uint64_t cb = rg_fmt_chunk_bytes<T>(part >= (uint32_t)SPMV_NSLAB, d_fmt);
+          for (uint32_t c0 = 0; c0 < d_nch; c0 += per) {
             RgBlk e = d;
-            e.off = d.off + (uint64_t)c0 * cb, e.nchunks = std::min(per, d.nchunks - c0), e.nsubs = d.nsubs | RG_PIECE;
+            e.off = d.off + (uint64_t)c0 * cb, e.nchunks = std::min(per, d_nch - c0) | (d_fmt << RG_FMT_SHIFT), e.nsubs = d.nsubs | RG_PIECE;
             h_q.push_back(e);
           }
           grp_clear[i] = 1;
@@ -879,7 +1114,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   }
   g->nq = (uint32_t)h_q.size();
   nonempty = 0;
-  for (const RgBlk& e : h_q) nonempty += e.nchunks != 0;
+  for (const RgBlk& e : h_q) nonempty += (e.nchunks & RG_NCHUNK_MASK) != 0;
   g->nonempty_blocks = nonempty;
   DevBuf pe, stream, vsrc, sub_head, grp_cp, cp, qblk;
   SPAM_TRY(qblk.alloc(((uint64_t)h_q.size() + 1) * sizeof(RgBlk)));
@@ -898,10 +1133,22 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_HIP_TRY(hipMemcpyAsync(grp_cp.p, h_grp_cp.data(), (uint64_t)ng * SPMV_NPART * 8, hipMemcpyHostToDevice, s));
   if (!h_sub_head.empty())
     SPAM_HIP_TRY(hipMemcpyAsync(sub_head.p, h_sub_head.data(), h_sub_head.size() * 4, hipMemcpyHostToDevice, s));
-  rg_fill_kernel<T><<<(unsigned)((g->padded + 255) / 256), 256, 0, s>>>(
-      keys_out.as<uint64_t>(), src_out.as<uint32_t>(), start.as<uint64_t>(), pe.as<uint64_t>(), blk.as<RgBlk>(), nb, first_wide,
-      first_short, (uint32_t)abits, (const T*)a->vals, fold ? (const T*)res->vals : nullptr, stream.as<unsigned char>(),
-      vsrc.as<uint32_t>(), g->padded);
+  // padding in front of every entry under its block's format, prefix-summed: an entry's position inside its block
+  DevBuf padv, pad_before, ptmp;
+  if (any_packed) {
+    SPAM_TRY(padv.alloc(n_all * 4));
+    SPAM_TRY(pad_before.alloc((n_all + 1) * 8));
+    SPAM_TRY(ptmp.alloc(scan_tmp_bytes(n_all)));
+    rg_padsel_kernel<<<(unsigned)((n_all + 255) / 256), 256, 0, s>>>(keys_out.as<uint64_t>(), n_all, blk.as<RgBlk>(), padv.as<uint32_t>());
+    SPAM_CHECK_LAUNCH();
+    SPAM_TRY(scan_u32_to_u64(padv.as<uint32_t>(), n_all, pad_before.as<uint64_t>(), ptmp.p, s));
+  }
+  SPAM_HIP_TRY(hipMemsetAsync(stream.p, 0, g->stream_bytes + 16, s));     // padding values are zero
+  SPAM_HIP_TRY(hipMemsetAsync(vsrc.p, 0xFF, g->padded * 4 + 16, s));      // ... and have no source (RG_NONE)
+  rg_fill_kernel<T><<<(unsigned)((n_all + 255) / 256), 256, 0, s>>>(
+      keys_out.as<uint64_t>(), src_out.as<uint32_t>(), start.as<uint64_t>(), pe.as<uint64_t>(),
+      any_packed ? pad_before.as<uint64_t>() : nullptr, blk.as<RgBlk>(), first_wide, first_short, (uint32_t)abits,
+      (const T*)a->vals, fold ? (const T*)res->vals : nullptr, stream.as<unsigned char>(), vsrc.as<uint32_t>(), n_all);
   SPAM_CHECK_LAUNCH();
   SPAM_HIP_TRY(hipStreamSynchronize(s));  // host vectors and temporaries go out of scope
   pc.stamp("    rg: bounds, offsets, stream fill (incl. allocations)");

@@ -292,10 +292,12 @@ def test_full_size_row_sum_property(spam, oracle):
 def test_scale22_rank_blocks_cfg4(spam, oracle):
     """BASELINE configs[3] (8 x MI355X, R-MAT scale 22: F = 1.46e11, nnz(C) = 7.2e10 = 864 GB, which only fits
     sharded) as far as one GPU can take it: the matrix is built at full size, cut into the 8 row blocks the 8-rank run
-    uses (rows_to_threads on F + 2300 per non-empty row, mul_hash.rs:52-62), and two of the per-rank products
-    C_r = A[block r] * B are run at full size on this GPU — the heaviest block (<= 137 GB of C) and a middle one.
-    Each is checked like the scale-20 product: row sums against A_r*(B*x) for a random x over ALL rows of the block,
-    and bounded row samples against the oracle (row_ptr exact, column sets, 1e-10, reference slot order bit-exact)."""
+    uses (rows_to_threads on F + row_overhead per non-empty row, mul_hash.rs:52-62), and ALL EIGHT per-rank products
+    C_r = A[block r] * B are run at full size on this GPU, one after another (the heaviest holds <= 137 GB of C).
+    Every block is checked by row sums against A_r*(B*x) for a random x over ALL its rows (column-sensitive), its
+    row_ptr is a prefix sum ending at nnz(C_r), its flop count equals the partition's, and the blocks tile C:
+    sum of nnz(C_r) = nnz(A*A) = 7.2e10, sum of F_r = F.  The heaviest block and a middle one also give three bounded
+    row samples each to the oracle (row_ptr exact, column sets, 1e-10, reference slot order bit-exact)."""
     import torch
     from sparse_matrix_amd import DeviceCsr, _lib
     from helpers import spgemm_rows_vs_oracle
@@ -304,7 +306,7 @@ def test_scale22_rank_blocks_cfg4(spam, oracle):
     A = synth.rmat(22, dtype=torch.float64, device=dev)
     n = A.rows
     dB = DeviceCsr.from_torch(n, n, A.row_ptr, A.col_idx, A.vals, True)
-    offs = dB.balanced_row_blocks(dB, 8, 2300)
+    offs = dB.balanced_row_blocks(dB, 8, 4000)
     assert offs[0] == 0 and offs[-1] == n and all(b > a for a, b in zip(offs[:-1], offs[1:]))
     b_host = A.cpu_numpy()
     x = synth.dense_vector(n, dtype=torch.float64, device=dev)
@@ -313,13 +315,15 @@ def test_scale22_rank_blocks_cfg4(spam, oracle):
     flops, _ = dB.rows_to_parts(dB, 1)
     cost = [int(flops[offs[r]:offs[r + 1]].sum()) for r in range(8)]
     heaviest = int(np.argmax([int(b_host[0][offs[r + 1]] - b_host[0][offs[r]]) for r in range(8)]))  # most entries of A
-    total_nnz_c = 0
-    for r in sorted({heaviest, 4}):
+    sampled = {heaviest, 4}
+    total_nnz_c, total_f = 0, 0
+    for r in range(8):
         lo, hi = offs[r], offs[r + 1]
         dAr = dB.row_block(lo, hi)
         C, st = dAr.spgemm(dB, sort_rows=False)
         assert st["flops_f"] == cost[r]
         total_nnz_c += st["nnz_c"]
+        total_f += st["flops_f"]
         want = torch.empty(hi - lo, dtype=torch.float64, device=dev)
         got = torch.empty(hi - lo, dtype=torch.float64, device=dev)
         dAr.spmv_dev(bx.data_ptr(), want.data_ptr())
@@ -327,16 +331,20 @@ def test_scale22_rank_blocks_cfg4(spam, oracle):
         torch.cuda.synchronize()
         rel = ((got - want).abs() / want.abs().clamp_min(1e-300)).max().item()
         assert rel <= F64_RTOL, (r, rel)
-        s, e = int(b_host[0][lo]), int(b_host[0][hi])
-        a_host = (b_host[0][lo:hi + 1] - b_host[0][lo], b_host[1][s:e], b_host[2][s:e])
-        for row_lo, target in (((hi - lo) // 2, 1e8), (0, 5e7), ((hi - lo) - max(1, (hi - lo) // 50), 3e7)):
-            spgemm_rows_vs_oracle(oracle, dAr, dB, C, a_host, b_host, row_lo, target)
+        if r in sampled:
+            s, e = int(b_host[0][lo]), int(b_host[0][hi])
+            a_host = (b_host[0][lo:hi + 1] - b_host[0][lo], b_host[1][s:e], b_host[2][s:e])
+            for row_lo, target in (((hi - lo) // 2, 1e8), (0, 5e7), ((hi - lo) - max(1, (hi - lo) // 50), 3e7)):
+                spgemm_rows_vs_oracle(oracle, dAr, dB, C, a_host, b_host, row_lo, target)
         rp = C.download_row_ptr().astype(np.int64)
         assert rp[-1] == st["nnz_c"] and np.all(np.diff(rp) >= 0)
         C.free()
         del C, dAr, want, got
-        _lib.check(_lib.load().spam_hip_trim())
-    assert total_nnz_c > 10_000_000_000
+        # (the output blocks go back to the library's allocator, which hands them to the next block's product when
+        # they fit and returns them to the driver by itself when a larger one does not)
+    _lib.check(_lib.load().spam_hip_trim())
+    assert total_f == int(flops.sum()) and total_f > 140_000_000_000
+    assert 71_000_000_000 < total_nnz_c < 73_000_000_000, total_nnz_c  # nnz(A*A) at scale 22 (7.2e10)
 
 
 def test_matrix_market_bench_shape(spam, oracle, tmp_path):

@@ -22,7 +22,8 @@ F32_RTOL = 1e-5
 
 ENV_KEYS = ("SPAM_SPMV_SLICED", "SPAM_SPMV_SLICE_KB", "SPAM_SPMV_LDS_KB", "SPAM_SPMV_LONG", "SPAM_SPMV_SLICED_TPB",
             "SPAM_SPMV_SLICED_NPT", "SPAM_SPMV_SLICED_WGS", "SPAM_SPMV_L0_KB", "SPAM_SPMV_PIPE", "SPAM_SPMV_RG",
-            "SPAM_SPMV_RG_EBLK", "SPAM_SPMV_RG_NT", "SPAM_SPMV_RG_K", "SPAM_SPMV_RG_ABITS", "SPAM_SPMV_RG_SHORT", "SPAM_SPMV_RG_ORDER")
+            "SPAM_SPMV_RG_EBLK", "SPAM_SPMV_RG_NT", "SPAM_SPMV_RG_K", "SPAM_SPMV_RG_ABITS", "SPAM_SPMV_RG_SHORT", "SPAM_SPMV_RG_ORDER",
+            "SPAM_SPMV_RG_FMT")
 
 
 @pytest.fixture(params=[1, 0], ids=["rowgroups", "tiles"])
@@ -422,3 +423,71 @@ def test_row_groups_giant_rows_run_as_pieces(spam, oracle, sliced_env, dtype):
             assert np.array_equal(y, ref)
         else:
             assert np.all(np.abs(y.astype(np.float64) - ref) <= (1e-12 if dtype == np.float64 else 2e-6) * np.abs(ref))
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["dense_blocks", "gappy", "rmat14"])
+def test_row_groups_packed_entry_words(spam, oracle, sliced_env, fmt, kind):
+    """The packed chunk formats of the row-group form (16- / 24-bit entry words: accumulator + slot DELTA, slots rebuilt by
+    wave prefix sums; padding entries bridge deltas that do not fit), each forced as the upper limit: f64 against the
+    oracle, Wrapping<i64> bit for bit, and an in-place value update through spam_csr_values_changed (the padded value
+    positions keep their sources).  dense_blocks: 40 000 rows over 3 000 columns — every block walks its table with
+    deltas of 0..2 (16-bit words); gappy: the same rows plus columns spread over 200 000 (deltas of hundreds: 24-bit
+    words, or padding under the 16-bit limit); rmat14: a mix, with hub rows and pieces."""
+    sliced_env(SLICE_KB=8, RG_FMT=fmt, RG_EBLK=4096)
+    if os.environ["SPAM_SPMV_RG"] != "1":
+        pytest.skip("row-group format")
+    rng = np.random.default_rng(17 + fmt)
+    if kind == "rmat14":
+        m = synth.rmat(14)
+        off, idx, val = csr_np(m)
+        rows, cols = m.rows, m.cols
+    else:
+        rows, cols = 40_000, (3_000 if kind == "dense_blocks" else 200_000)
+        per = rng.integers(3, 24, rows)
+        off = np.concatenate([[0], np.cumsum(per)]).astype(np.uint64)
+        pieces = []
+        for r in range(rows):
+            hot = rng.choice(3_000, size=min(int(per[r]), 3_000), replace=False)
+            if kind == "gappy" and r % 3 == 0:
+                hot[: len(hot) // 2] = rng.choice(np.arange(3_000, cols), size=len(hot) // 2, replace=False)
+            pieces.append(np.sort(np.unique(hot)))
+        per = np.array([len(p) for p in pieces])
+        off = np.concatenate([[0], np.cumsum(per)]).astype(np.uint64)
+        idx = np.concatenate(pieces).astype(np.uint64)
+        val = rng.uniform(0.5, 1.5, idx.size)
+    info = _check(spam, oracle, off, idx, val, rows, cols, True, F64_RTOL)
+    assert info["row_groups"]["active"]
+    # Wrapping<i64>: exact, and again after the values changed in place
+    vi = rng.integers(-2**62, 2**62, idx.size, dtype=np.int64)
+    xi = rng.integers(-2**62, 2**62, cols, dtype=np.int64)
+    dev = torch.device("cuda", 0)
+    tv = torch.from_numpy(vi).to(dev)
+    B = spam.DeviceCsr.from_torch(rows, cols, torch.from_numpy(off.astype(np.int64)).to(dev),
+                                  torch.from_numpy(idx.astype(np.int32)).to(dev), tv, True)
+    tx = torch.from_numpy(xi).to(dev)
+    ty = torch.empty(rows, dtype=torch.int64, device=dev)
+    B.spmv_prepare(tx.data_ptr())
+    assert B.spmv_plan_info()["sliced"]["row_groups"]["active"]
+    B.spmv_dev(tx.data_ptr(), ty.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(ty.cpu().numpy(), oracle.spmv((off, idx, vi), xi))
+    sb0 = B.spmv_plan_info()["sliced"]["row_groups"]["stream_bytes"]
+    tv.mul_(5)
+    B.values_changed()
+    B.spmv_dev(tx.data_ptr(), ty.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(ty.cpu().numpy(), oracle.spmv((off, idx, vi * 5), xi))
+    # the packed formats must actually shrink the stream where the deltas are small
+    if kind == "dense_blocks":
+        os.environ["SPAM_SPMV_RG_FMT"] = "0"
+        B0 = spam.DeviceCsr.from_torch(rows, cols, torch.from_numpy(off.astype(np.int64)).to(dev),
+                                       torch.from_numpy(idx.astype(np.int32)).to(dev), tv, True)
+        B0.spmv_prepare(tx.data_ptr())
+        plain = B0.spmv_plan_info()["sliced"]["row_groups"]["stream_bytes"]
+        if fmt == 2:
+            assert sb0 < 0.90 * plain, (sb0, plain)
+        elif fmt == 1:
+            assert sb0 < 0.96 * plain, (sb0, plain)
+        else:
+            assert sb0 == plain
