@@ -198,6 +198,8 @@ struct RgPlan {
   uint64_t* grp_cp = nullptr;       // u64[ng][NPART]: first pair of every (group, part) block in cp
   void* cp = nullptr;               // T[npairs]: the pair sums of one SpMV
   uint32_t* vsrc = nullptr;         // u32[padded]: source entry of every value position (spam_csr_values_changed)
+  uint64_t* piece_pairs = nullptr;  // u64[n_piece_pairs]: pairs of the blocks run in pieces (their sums meet by atomic adds):
+  uint32_t n_piece_pairs = 0;       // set to zero by the first kernel of every product
 };
 void rg_plan_free(RgPlan* g);
 // *out stays null when the matrix does not qualify (the caller then builds the tile form)

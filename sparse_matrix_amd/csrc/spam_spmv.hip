@@ -767,7 +767,8 @@ struct SlicedPlan {
                                 // stay in the CU's 32 KB L1; with use_lds every workgroup copies them to LDS instead)
   bool use_lds = false;
   bool pipelined = true;        // software-pipelined persistent kernel (SPAM_SPMV_PIPE=0: the plain loop)
-  uint32_t ns = 0;              // non-empty short rows
+  uint32_t ns = 0;              // short rows (with y_covered: the empty rows too, as rows of zero entries)
+  bool y_covered = false;       // every row of y is written by the reduce or a short-row block: no zero-fill of y per product
   uint32_t nl = 0;              // long rows
   uint32_t long_min = 0;        // rows with >= long_min entries are long
   int tpb = 256, npt = 16;
@@ -1046,6 +1047,10 @@ __global__ __launch_bounds__(256) void spmv_short_rows_kernel(const uint32_t* __
   if (i >= ns) return;
   const uint32_t s = res_ptr[i], e = res_ptr[i + 1];
   const uint32_t r = short_rows[i];
+  if (s >= e) {  // a row of zero entries (listed when the plan covers all of y): nothing to gather
+    y[r] = T(0);
+    return;
+  }
   const uint32_t s1 = s + 1 < e ? s + 1 : s;
   const uint32_t c0 = col[s], c1 = col[s1];
   const T v0 = val[s], v1 = val[s1];
@@ -1061,9 +1066,11 @@ __global__ __launch_bounds__(256) void spmv_short_rows_kernel(const uint32_t* __
 template <class T>
 __global__ void sliced_build_tables_kernel(const T* __restrict__ x, const uint32_t* __restrict__ dest, uint32_t cols,
                                            T* __restrict__ xh, uint32_t* __restrict__ heads, T* __restrict__ y,
-                                           uint32_t rows) {
+                                           uint32_t rows, T* __restrict__ cp, const uint64_t* __restrict__ piece_pairs,
+                                           uint32_t n_piece) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= NPART) heads[i * HEAD_STRIDE] = 0;
+  if (i < n_piece) cp[piece_pairs[i]] = T(0);  // pair sums that pieces of a block add to start every product at zero
   if (i < rows) y[i] = T(0);
   if (i >= cols) return;
   const uint32_t d = dest[i];
@@ -1074,11 +1081,13 @@ __global__ void sliced_build_tables_kernel(const T* __restrict__ x, const uint32
 template <class T, int V>
 __global__ void sliced_build_tables_vec_kernel(const T* __restrict__ x, const uint32_t* __restrict__ dest, uint32_t cols,
                                                T* __restrict__ xh, uint32_t* __restrict__ heads, T* __restrict__ y,
-                                               uint32_t rows) {
+                                               uint32_t rows, T* __restrict__ cp, const uint64_t* __restrict__ piece_pairs,
+                                               uint32_t n_piece) {
   typedef T TV __attribute__((ext_vector_type(V)));
   typedef uint32_t UV __attribute__((ext_vector_type(V)));
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, i = j * V;
   if (j <= NPART) heads[j * HEAD_STRIDE] = 0;
+  if (j < n_piece) cp[piece_pairs[j]] = T(0);  // pair sums that pieces of a block add to start every product at zero
   if (i + V <= rows) {
     TV z;
 #pragma unroll
@@ -1137,16 +1146,18 @@ __global__ void sliced_assign_kernel(const uint32_t* __restrict__ f0, const uint
     code[i] = (uint32_t)i, slab[i] = (uint8_t)NSLAB, dest[i] = NO_DEST;
   }
 }
+// include_empty: rows without entries join the short rows (as rows of zero entries): every row of y is then written by
+// the kernel that owns it — the reduce (sliced rows) or a short-row block — and the zero-fill of y is not needed.
 __global__ void sliced_row_flags_kernel(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t long_min,
-                                        uint32_t* __restrict__ is_long, uint32_t* __restrict__ short_len,
-                                        uint32_t* __restrict__ is_short) {
+                                        int include_empty, uint32_t* __restrict__ is_long,
+                                        uint32_t* __restrict__ short_len, uint32_t* __restrict__ is_short) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   const uint32_t len = row_ptr[r + 1] - row_ptr[r];
   const bool lg = len >= long_min;
   is_long[r] = lg;
   short_len[r] = lg ? 0u : len;
-  is_short[r] = !lg && len > 0;
+  is_short[r] = !lg && (len > 0 || include_empty);
 }
 // compact row list + compact row_ptr of the non-empty short rows
 __global__ void sliced_short_list_kernel(const uint32_t* __restrict__ is_short, const uint64_t* __restrict__ pos,
@@ -1426,8 +1437,12 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   SPAM_TRY(posl.alloc(((uint64_t)rows + 1) * 8));
   SPAM_TRY(res64.alloc(((uint64_t)rows + 1) * 8));
   SPAM_TRY(res32.alloc(((uint64_t)rows + 1) * 4));
-  sliced_row_flags_kernel<<<gr, 256, 0, s>>>(a->row_ptr32, rows, q->long_min, is_long.as<uint32_t>(), short_len.as<uint32_t>(),
-                                             is_short.as<uint32_t>());
+  // (round 4 measured: listing the empty rows as short rows of zero entries, so that every row of y has a writer and the
+  // zero-fill of y can go, changes nothing on the bench matrix — 0.563 against 0.561 ms: the 80 MB of zeros it saves
+  // come back as row lists and scattered stores — so the zero-fill stays)
+  const bool include_empty = false;
+  sliced_row_flags_kernel<<<gr, 256, 0, s>>>(a->row_ptr32, rows, q->long_min, include_empty ? 1 : 0, is_long.as<uint32_t>(),
+                                             short_len.as<uint32_t>(), is_short.as<uint32_t>());
   SPAM_CHECK_LAUNCH();
   SPAM_TRY(scan_u32_to_u64(is_long.as<uint32_t>(), rows, posl.as<uint64_t>(), tmp.p, s));
   SPAM_TRY(scan_u32_to_u64(is_short.as<uint32_t>(), rows, poss.as<uint64_t>(), tmp.p, s));
@@ -1475,6 +1490,7 @@ static int sliced_analyse(const spam_csr* a, const SpmvKnobs& kn, int force, hip
   // -- the long rows: row-group form (spam_spmv_rg.hip) or slab CSRs ------------------------------------------
   if (kn.rg)
     SPAM_TRY(rg_build<T>(a, slab.as<uint8_t>(), code.as<uint32_t>(), long_rows.as<uint32_t>(), nl, S, res, q->ns, kn.rgk, s, &q->rg));
+  q->y_covered = include_empty && q->rg && q->rg->ngs > 0;  // (the short-row blocks of the row-group kernel hold every row that is not sliced)
   pc.stamp("  sliced: row-group plan (rg_build)");
   if (!q->rg && !force && !tile_form_candidate) return SPAM_OK;  // (row groups declined; the guard frees q)
   DevBuf cnt8, sc64, srow, sbase_d;
@@ -1618,12 +1634,17 @@ static int sliced_run(const spam_csr* a, const SlicedPlan* q, const T* x, T* y, 
   const uint32_t cols = (uint32_t)a->cols;
   const uint32_t rows = (uint32_t)a->rows;
   constexpr int V = 16 / (int)sizeof(T);
+  const uint32_t zrows = q->y_covered ? 0u : rows;  // rows of y to zero here: none when every row has an owner that writes it
+  T* cp = q->rg ? (T*)q->rg->cp : nullptr;
+  const uint64_t* pp = q->rg ? q->rg->piece_pairs : nullptr;
+  const uint32_t npp = q->rg ? q->rg->n_piece_pairs : 0u;
   if ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0) {
-    const uint64_t nthr = ((uint64_t)std::max(cols, rows) + V - 1) / V;
+    const uint64_t nthr = std::max<uint64_t>(((uint64_t)std::max(cols, zrows) + V - 1) / V, npp);
     sliced_build_tables_vec_kernel<T, V><<<(unsigned)((std::max<uint64_t>(nthr, NPART + 1) + 255) / 256), 256, 0, s>>>(
-        x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
+        x, q->dest, cols, (T*)q->xh, q->heads, y, zrows, cp, pp, npp);
   } else {
-    sliced_build_tables_kernel<T><<<(unsigned)(((uint64_t)std::max(cols, rows) + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, rows);
+    const uint64_t nthr = std::max<uint64_t>(std::max<uint64_t>(std::max(cols, zrows), npp), NPART + 1);
+    sliced_build_tables_kernel<T><<<(unsigned)((nthr + 255) / 256), 256, 0, s>>>(x, q->dest, cols, (T*)q->xh, q->heads, y, zrows, cp, pp, npp);
   }
   SPAM_CHECK_LAUNCH();
   // (running the short rows beside the slab kernel on a second stream was measured 3 % slower than one after the other)
@@ -1763,10 +1784,12 @@ static int spmv_typed(const spam_csr* a, const OffT* row_ptr, const T* x, T* y, 
 
 // spam_spmv_prepare: the analysis step of CSR-adaptive, done once per matrix and never inside spam_spmv_dev.
 //   * environment knobs are read here, once;
-//   * hot-column table of the plain path (column histogram + threshold bisection: host-synchronised);
+//   * hot-column table of the plain path (one column histogram + a sort of the counts: host-synchronised);
 //   * the XCD-sliced structure where the matrix qualifies (SPAM_SPMV_SLICED = 1: kept only if three timed runs on `x`
 //     beat the plain path by more than 3 %; 2: always; 0: never).  x = NULL times on a vector of ones.
-// The choice fixes the summation order of every later SpMV on this handle (results are deterministic per plan).
+// The choice fixes the path of every later SpMV on this handle.  Summation order: the plain path and the tile form
+// (SPAM_SPMV_RG=0) are deterministic per plan; the row-group form (the default for sliced plans) adds f32 / f64 products
+// with LDS atomics, so its results are reproducible to rounding, not bit for bit, from run to run (i64: exact).
 template <class T, class OffT>
 static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream_t s) {
   std::lock_guard<std::mutex> lk(a->plan_mu);
@@ -1789,7 +1812,14 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
   pc.stamp("row -> tile map");
   ColStats cs;
   // (both analyses give up on 2^31 columns and more, and neither needs the counts of a matrix without entries)
-  const bool want_stats = a->cols < 0x7FFFFFFFull && a->nnz > 0 && (p->knobs.hot_kb > 0 || p->knobs.sliced);
+  // ... nor where neither analysis can use them: the hot-column table needs more columns than twice its slots, the sliced
+  // candidates start at 3 M entries (row groups) / an x beyond one L2 (tile form) unless forced
+  const uint64_t hot_kmax = (uint64_t)(p->knobs.hot_kb > 0 ? p->knobs.hot_kb : 0) * 1024 / sizeof(T);
+  const bool hot_eligible = p->knobs.hot_kb > 0 && a->cols > 2 * hot_kmax;
+  const bool sliced_eligible = p->knobs.sliced == 2 ||
+                               (p->knobs.sliced == 1 && a->row_ptr32 && a->nnz >= (1u << 20) &&
+                                (p->knobs.rg ? a->nnz >= (3u << 20) : a->cols * sizeof(T) > (4u << 20)));
+  const bool want_stats = a->cols < 0x7FFFFFFFull && a->nnz > 0 && (hot_eligible || sliced_eligible);
   if (want_stats) SPAM_TRY(col_stats(a, &cs, s));
   pc.stamp("column histogram + sort");
   SPAM_TRY(spmv_hot_analyse<T>(a, p, p->knobs.hot_kb, s, want_stats ? &cs : nullptr));
@@ -1801,7 +1831,7 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
     const T* xt = x;
     float ms_plain = 0.f;
     bool plain_is_fast = false;
-    if (sl_cfg == 1 && a->nnz >= (1u << 20)) {
+    if (sl_cfg == 1 && sliced_eligible) {
       // The plain path first: a matrix it already streams at 4.5 TB/s of algorithmic bytes (banded ones: 5.3) has
       // nothing to gain from tables or LDS accumulators, and building the sliced structure only to discard it would
       // cost the caller tens to hundreds of milliseconds.
@@ -1821,7 +1851,7 @@ static int prepare_typed(spam_csr* a, const OffT* row_ptr, const T* x, hipStream
       plain_is_fast = ms_plain > 0.f && bytes / ((double)ms_plain * 1e-3) >= 4.5e12;
       pc.stamp("plain path timed");
     }
-    if (!plain_is_fast) SPAM_TRY(sliced_analyse<T>(a, p->knobs, sl_cfg == 2, s, &q, want_stats ? &cs : nullptr));
+    if (!plain_is_fast && sliced_eligible) SPAM_TRY(sliced_analyse<T>(a, p->knobs, sl_cfg == 2, s, &q, want_stats ? &cs : nullptr));
     pc.stamp("sliced analysis (all of it)");
     if (q && sl_cfg == 1) {  // keep it only if it is faster on this matrix
       struct QGuard {

@@ -74,19 +74,22 @@ __host__ __device__ constexpr uint32_t rg_chunk_bytes(bool wide) {
 //   fmt 0: 32-bit words, slot << abits | accumulator (the plain format above), 12 bytes per f64 entry;
 //   fmt 1: 24-bit words, delta (11 bits) << 13 | accumulator, 11 bytes per f64 entry;
 //   fmt 2: 16-bit words, delta (3 bits) << 13 | accumulator, 10 bytes per f64 entry (6 per f32 entry instead of 8).
-// A packed chunk starts with a 16-byte header (word 0: the absolute slot of its first entry, whose own delta field is
-// 0); lane l's four words are bytes [HDR + 4 b l, HDR + 4 b (l + 1)) (b = 2 or 3 bytes per word), its k-th word sorted
-// entry 64 k + l as before, so a gather instruction still covers 64 consecutive sorted entries.  A delta that does not
+// The absolute slot of a packed chunk's first entry (whose own delta field is 0) is kept out of line, in a header array at
+// the start of the block (one u32 per chunk, padded to 128 bytes), so that every chunk is a whole number of 128-byte
+// lines (2560 / 2816 bytes for f64) and starts on one — with the header inside, every chunk straddled two lines that its
+// neighbours, streamed by other wavefronts with non-temporal loads, fetched again: 6 % slower than the plain format
+// instead of faster.  Lane l's four words are bytes [4 b l, 4 b (l + 1)) of the chunk (b = 2 or 3 bytes per word), its
+// k-th word sorted entry 64 k + l as before, so a gather instruction still covers 64 consecutive sorted entries.  A delta that does not
 // fit is bridged by PADDING entries (spare accumulator, value 0, delta 7 / 2047); rg_build picks per block the format
 // with the fewest bytes (sparse blocks keep fmt 0).  The slots are rebuilt by four wave prefix sums per chunk (DPP).
 constexpr uint32_t RG_FMT_SHIFT = 30, RG_NCHUNK_MASK = (1u << RG_FMT_SHIFT) - 1u;  // RgBlk::nchunks carries the format
-constexpr uint32_t RG_PK_HDR = 16, RG_PK_ACC_BITS = 13, RG_PK_ACC_MASK = (1u << RG_PK_ACC_BITS) - 1u;
+constexpr uint32_t RG_PK_ACC_BITS = 13, RG_PK_ACC_MASK = (1u << RG_PK_ACC_BITS) - 1u;
 __host__ __device__ constexpr uint32_t rg_fmt_word_bytes(uint32_t fmt) { return fmt == 2 ? 2u : fmt == 1 ? 3u : 4u; }
 __host__ __device__ constexpr uint32_t rg_fmt_max_delta(uint32_t fmt) { return fmt == 2 ? 7u : 2047u; }
 // byte offset of the value array inside a chunk / size of a chunk, by format (wide: the cold part and the short rows)
 template <class T>
 __host__ __device__ constexpr uint32_t rg_fmt_voff(bool wide, uint32_t fmt) {
-  return wide ? 1536u : fmt == 0 ? 1024u : RG_PK_HDR + 256u * rg_fmt_word_bytes(fmt);
+  return wide ? 1536u : 256u * rg_fmt_word_bytes(fmt);
 }
 template <class T>
 __host__ __device__ constexpr uint32_t rg_fmt_chunk_bytes(bool wide, uint32_t fmt) {
@@ -123,6 +126,7 @@ struct RgBlk {
   uint32_t nheads;   // pairs of the block = head accumulators (short-row blocks: rows)
   uint32_t nsubs;    // extra accumulators behind the heads; bit 31 (queue entries only): a PIECE of a block, see RG_PIECE
   uint32_t sub0;     // their heads: sub_head[sub0 ..)
+  uint64_t hdr;      // packed formats: byte offset of the block's chunk headers in the stream (one u32 per chunk: first slot)
 };
 // A block of a few rows and very many entries (a row longer than a whole group's share: its group holds little else) would
 // keep one workgroup busy long after the others are done.  The kernel's queue therefore lists such a block as several
@@ -130,14 +134,14 @@ struct RgBlk {
 // device-scope atomics (a handful of values per piece); the reduce kernel sets those pairs back to zero once it has read them.
 constexpr uint32_t RG_PIECE = 0x80000000u;
 constexpr uint32_t RG_PIECE_MAX_HEADS = 64;
-static_assert(sizeof(RgBlk) == 32, "RgBlk layout");
+static_assert(sizeof(RgBlk) == 40, "RgBlk layout");
 
 // Tile t = rank slots [64 t, 64 t + 64), all of one group (a group starts on a multiple of 64: the slots skipped in
 // front of it hold no row)
 struct RgTile {
   uint32_t grp;
   uint16_t base[SPMV_NPART];  // pairs of the group's earlier tiles, per part
-  uint16_t clear;             // 1: the group has blocks run in pieces — the reduce zeroes the pairs it has read
+  uint16_t clear;             // (unused since round 4: the pairs that pieces add to are zeroed at the start of every product)
 };
 static_assert(sizeof(RgTile) == 24, "RgTile layout");
 
@@ -245,17 +249,17 @@ __device__ __forceinline__ void rg_stream(const unsigned char* p0, uint32_t nchu
 // base plus the running sum of the delta fields in sorted order (entry 64 k + l = word k of lane l): one wave prefix sum
 // per k, the total of each carried into the next.
 template <class T, int NT, int K, int WB>
-__device__ __forceinline__ void rg_stream_packed(const unsigned char* p0, uint32_t nchunks, int wave, int lane,
-                                                 const T RG_GLB* xg, typename RgAcc<T>::type* acc) {
+__device__ __forceinline__ void rg_stream_packed(const unsigned char* p0, const uint32_t* __restrict__ hdr, uint32_t nchunks,
+                                                 int wave, int lane, const T RG_GLB* xg, typename RgAcc<T>::type* acc) {
   typedef RgAcc<T> A;
   constexpr int nw = NT / 64;
-  constexpr uint32_t VOFF = RG_PK_HDR + 256u * (uint32_t)WB, CB = VOFF + 256u * (uint32_t)sizeof(T);
+  constexpr uint32_t VOFF = 256u * (uint32_t)WB, CB = VOFF + 256u * (uint32_t)sizeof(T);
   auto load_words = [&](const unsigned char* q, uint32_t (&e)[4]) {
     if constexpr (WB == 2) {
-      const u32x2 w = __builtin_nontemporal_load((const u32x2*)(q + RG_PK_HDR + 8 * lane));
+      const u32x2 w = __builtin_nontemporal_load((const u32x2*)(q + 8 * lane));
       e[0] = w.x & 0xFFFFu, e[1] = w.x >> 16, e[2] = w.y & 0xFFFFu, e[3] = w.y >> 16;
     } else {
-      const uint32_t* wp = (const uint32_t*)(q + RG_PK_HDR + 12 * lane);  // (three 4-byte nt loads: merged into one dwordx3)
+      const uint32_t* wp = (const uint32_t*)(q + 12 * lane);  // (three 4-byte nt loads: merged into one dwordx3)
       RgU3 w;
       w.x = __builtin_nontemporal_load(wp), w.y = __builtin_nontemporal_load(wp + 1), w.z = __builtin_nontemporal_load(wp + 2);
       e[0] = w.x & 0xFFFFFFu, e[1] = (w.x >> 24) | ((w.y & 0xFFFFu) << 8), e[2] = (w.y >> 16) | ((w.z & 0xFFu) << 16), e[3] = w.z >> 8;
@@ -277,7 +281,7 @@ __device__ __forceinline__ void rg_stream_packed(const unsigned char* p0, uint32
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const unsigned char* q = p0 + (uint64_t)(c + (uint32_t)k * nw) * CB;
-      base[k] = *(const uint32_t*)q;  // (uniform address)
+      base[k] = hdr[c + (uint32_t)k * nw];  // (uniform address)
       load_words(q, e[k]);
       rg_load_vals<T>(q + VOFF, lane, v[k]);
     }
@@ -297,7 +301,7 @@ __device__ __forceinline__ void rg_stream_packed(const unsigned char* p0, uint32
     const unsigned char* q = p0 + (uint64_t)c * CB;
     uint32_t e[4], sl[4];
     T v[4];
-    const uint32_t base = *(const uint32_t*)q;
+    const uint32_t base = hdr[c];
     load_words(q, e);
     rg_load_vals<T>(q + VOFF, lane, v);
     slots_of(base, e, sl);
@@ -340,7 +344,8 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
     }
     const RgBlk* bd = P.blk + (P.qbase[part] + g);
     const uint32_t nchunks = bd->nchunks & RG_NCHUNK_MASK, fmt = bd->nchunks >> RG_FMT_SHIFT;
-    if (nchunks == 0) continue;  // no entry of this group in this part (its pairs, if any, stay zero)
+    if (nchunks == 0 && !is_short) continue;  // no entry of this group in this part (its pairs, if any, stay zero); a
+                                              // short-row block without entries still owes y its zeros
     const uint64_t off = bd->off, cp0 = bd->cp0;
     const uint32_t nheads = bd->nheads, nsubs = bd->nsubs & ~RG_PIECE, sub0 = bd->sub0;
     const bool piece = (bd->nsubs & RG_PIECE) != 0u;
@@ -353,9 +358,9 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
     if (part >= (uint32_t)SPMV_NSLAB)
       rg_stream<T, NT, K, true>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[SPMV_NSLAB], acc, P.abits);
     else if (fmt == 2)  // (uniform: a block has one format)
-      rg_stream_packed<T, NT, K, 2>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc);
+      rg_stream_packed<T, NT, K, 2>(P.stream + off, (const uint32_t*)(P.stream + bd->hdr), nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc);
     else if (fmt == 1)
-      rg_stream_packed<T, NT, K, 3>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc);
+      rg_stream_packed<T, NT, K, 3>(P.stream + off, (const uint32_t*)(P.stream + bd->hdr), nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc);
     else
       rg_stream<T, NT, K, false>(P.stream + off, nchunks, wave, lane, (const T RG_GLB*)P.base[part], acc, P.abits);
     __syncthreads();
@@ -394,7 +399,7 @@ template <class T>
 __global__ __launch_bounds__(256) void spmv_rg_reduce_kernel(const RgTile* __restrict__ tiles, uint32_t ntiles,
                                                              const uint16_t* __restrict__ mask_slot,
                                                              const uint32_t* __restrict__ slot_rows,
-                                                             const uint64_t* __restrict__ grp_cp, T* __restrict__ cp,
+                                                             const uint64_t* __restrict__ grp_cp, const T* __restrict__ cp,
                                                              T* __restrict__ y) {
   // (the tile index is wave-uniform: as a scalar, the descriptor and the nine block bases are scalar loads and leave the
   // vector-memory pipeline to the masks, rows, pairs and the store)
@@ -413,7 +418,6 @@ __global__ __launch_bounds__(256) void spmv_rg_reduce_kernel(const RgTile* __res
     const uint64_t bal = __ballot(has);
     const uint64_t at = gc[p] + tl.base[p] + (uint64_t)__popcll(bal & lt);
     v[p] = has ? cp[at] : T(0);
-    if (tl.clear && has) cp[at] = T(0);  // (uniform flag) pairs that pieces add to start the next product from zero
   }
   T s = v[0];
 #pragma unroll
@@ -631,12 +635,12 @@ __global__ void rg_fill_kernel(const uint64_t* __restrict__ keys, const uint32_t
     } else if (fmt == 0) {
       reinterpret_cast<uint32_t*>(c)[wpos] = (slot << abits) | acc;
     } else {
-      if (w == 0) {  // the chunk's first entry: absolute slot in the header, no delta
-        *reinterpret_cast<uint32_t*>(c) = slot;
+      if (w == 0) {  // the chunk's first entry: absolute slot in the block's header array, no delta
+        reinterpret_cast<uint32_t*>(stream + bd.hdr)[chunk] = slot;
         delta = 0;
       }
       const uint32_t word = (delta << RG_PK_ACC_BITS) | acc;
-      unsigned char* d = c + RG_PK_HDR + wb * wpos;
+      unsigned char* d = c + wb * wpos;
       if (fmt == 2) {
         *reinterpret_cast<uint16_t*>(d) = (uint16_t)word;
       } else {
@@ -701,7 +705,10 @@ static int rg_launch_or_grid(const RgPlan* g, const RgArgs<T>* args, hipStream_t
     SPAM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, g->lds_bytes));
     SPAM_HIP_TRY(hipGetDevice(&dev));
     SPAM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (per_cu < 1) return set_error(SPAM_E_HIP, "row-group SpMV kernel does not fit a CU (%u B of LDS)", g->lds_bytes);
+    if (per_cu < 1) {  // (a device with less LDS than gfx950: declined, the caller keeps the tile form)
+      *grid_out = 0;
+      return SPAM_OK;
+    }
     uint64_t n = (uint64_t)per_cu * (uint64_t)cus;
     if (n > g->nonempty_blocks) n = g->nonempty_blocks;
     *grid_out = (unsigned)std::max<uint64_t>(n, 1);
@@ -721,6 +728,10 @@ static int rg_dispatch(const RgPlan* g, const RgArgs<T>* args, hipStream_t s, un
   SPAM_RG_VARIANT(1024, 4);
   SPAM_RG_VARIANT(256, 4);
 #undef SPAM_RG_VARIANT
+  if (grid_out) {  // an SPAM_SPMV_RG_NT / _K combination that is not compiled: declined like any other non-qualifying case
+    *grid_out = 0;
+    return SPAM_OK;
+  }
   return set_error(SPAM_E_INVALID, "no row-group SpMV kernel for %d threads x %d chunks", g->nt, g->k);
 }
 
@@ -746,7 +757,7 @@ int sort_u32_desc(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t
 
 void rg_plan_free(RgPlan* g) {
   if (!g) return;
-  void* ptrs[] = {g->stream, g->blk, g->qblk, g->pe, g->sub_head, g->slot_rows, g->mask_slot, g->tiles, g->grp_cp, g->cp, g->vsrc};
+  void* ptrs[] = {g->stream, g->blk, g->qblk, g->pe, g->sub_head, g->slot_rows, g->mask_slot, g->tiles, g->grp_cp, g->cp, g->vsrc, g->piece_pairs};
   for (void* p : ptrs)
     if (p) dev_free(p);
   delete g;
@@ -1061,17 +1072,18 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
     uint32_t fmt = 0;
     uint64_t nel = cnt, bytes = ((cnt + 255) / 256) * rg_chunk_bytes<T>(wide);
     if (!wide && cnt > 0 && fmt_max > 0) {
-      const uint64_t n24 = cnt + h24[b], b24 = ((n24 + 255) / 256) * rg_fmt_chunk_bytes<T>(false, 1);
-      if (b24 < bytes && n24 < (1ull << 38)) fmt = 1, nel = n24, bytes = b24;
+      const uint64_t n24 = cnt + h24[b], c24 = (n24 + 255) / 256, b24 = c24 * rg_fmt_chunk_bytes<T>(false, 1) + ((c24 * 4 + 127) / 128) * 128;
+      if (b24 < bytes && n24 < (1ull << 38)) fmt = 1, nel = n24, bytes = c24 * rg_fmt_chunk_bytes<T>(false, 1);
       if (fmt_max > 1) {
-        const uint64_t n16 = cnt + h16[b], b16 = ((n16 + 255) / 256) * rg_fmt_chunk_bytes<T>(false, 2);
-        if (b16 < bytes && n16 < (1ull << 38)) fmt = 2, nel = n16, bytes = b16;
+        const uint64_t n16 = cnt + h16[b], c16 = (n16 + 255) / 256, b16 = c16 * rg_fmt_chunk_bytes<T>(false, 2) + ((c16 * 4 + 127) / 128) * 128;
+        if (b16 < bytes + (fmt ? ((nel + 255) / 256 * 4 + 127) / 128 * 128 : 0) && n16 < (1ull << 38)) fmt = 2, nel = n16, bytes = c16 * rg_fmt_chunk_bytes<T>(false, 2);
       }
     }
     const uint64_t nch = (nel + 255) / 256;
     if (nch > RG_NCHUNK_MASK) return SPAM_OK;  // (a block of 2^38 entries: the caller keeps the tile form)
-    h_blk[b].off = off, h_blk[b].nchunks = (uint32_t)nch | (fmt << RG_FMT_SHIFT);
-    off += bytes;
+    const uint64_t hdr_bytes = fmt ? ((nch * 4 + 127) / 128) * 128 : 0;
+    h_blk[b].hdr = off, h_blk[b].off = off + hdr_bytes, h_blk[b].nchunks = (uint32_t)nch | (fmt << RG_FMT_SHIFT);
+    off += hdr_bytes + bytes;
     h_pe[b + 1] = h_pe[b] + nch * 256;
     nonempty += cnt != 0;
     fmt_entries[fmt] += cnt, fmt_pads += nel - cnt;
@@ -1087,6 +1099,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   std::vector<RgBlk> h_q;
   h_q.reserve((size_t)nb + 64);
   std::vector<char> grp_clear(ng, 0);
+  std::vector<uint64_t> h_piece_pairs;  // pairs that pieces ADD to: zeroed at the start of every product (sliced_build_tables)
   {
     const uint32_t piece_chunks = (uint32_t)std::max<uint64_t>(1, eblk / 256);
     for (uint32_t part = 0; part <= (uint32_t)SPMV_NPART; ++part) {
@@ -1100,23 +1113,30 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
           const uint64_t cb = rg_fmt_chunk_bytes<T>(part >= (uint32_t)SPMV_NSLAB, d_fmt);
           for (uint32_t c0 = 0; c0 < d_nch; c0 += per) {
             RgBlk e = d;
-            e.off = d.off + (uint64_t)c0 * cb, e.nchunks = std::min(per, d_nch - c0) | (d_fmt << RG_FMT_SHIFT), e.nsubs = d.nsubs | RG_PIECE;
+            e.off = d.off + (uint64_t)c0 * cb, e.hdr = d.hdr + (uint64_t)c0 * 4, e.nchunks = std::min(per, d_nch - c0) | (d_fmt << RG_FMT_SHIFT), e.nsubs = d.nsubs | RG_PIECE;
             h_q.push_back(e);
           }
           grp_clear[i] = 1;
+          for (uint32_t hh = 0; hh < d.nheads; ++hh) h_piece_pairs.push_back(d.cp0 + hh);
         } else {
           h_q.push_back(d);
         }
       }
       g->qcount[part] = (uint32_t)h_q.size() - g->qbase[part];
     }
-    for (RgTile& t : h_tiles) t.clear = (uint16_t)grp_clear[t.grp];
+    for (RgTile& t : h_tiles) t.clear = 0;  // (round 3: the reduce set those pairs back to zero — a product then depended on
+                                            // its predecessor's epilogue having run; now every product zeroes them first)
   }
   g->nq = (uint32_t)h_q.size();
   nonempty = 0;
   for (const RgBlk& e : h_q) nonempty += (e.nchunks & RG_NCHUNK_MASK) != 0;
   g->nonempty_blocks = nonempty;
   DevBuf pe, stream, vsrc, sub_head, grp_cp, cp, qblk;
+  DevBuf piece_pairs;
+  SPAM_TRY(piece_pairs.alloc((h_piece_pairs.size() + 1) * 8));
+  if (!h_piece_pairs.empty())
+    SPAM_HIP_TRY(hipMemcpyAsync(piece_pairs.p, h_piece_pairs.data(), h_piece_pairs.size() * 8, hipMemcpyHostToDevice, s));
+  g->n_piece_pairs = (uint32_t)h_piece_pairs.size();
   SPAM_TRY(qblk.alloc(((uint64_t)h_q.size() + 1) * sizeof(RgBlk)));
   SPAM_HIP_TRY(hipMemcpyAsync(qblk.p, h_q.data(), h_q.size() * sizeof(RgBlk), hipMemcpyHostToDevice, s));
   SPAM_HIP_TRY(hipMemcpyAsync(tiles.p, h_tiles.data(), (uint64_t)ntiles * sizeof(RgTile), hipMemcpyHostToDevice, s));  // (with the clear flags)
@@ -1163,8 +1183,10 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   g->grp_cp = grp_cp.as<uint64_t>(), grp_cp.release();
   g->cp = cp.release();
   g->vsrc = vsrc.as<uint32_t>(), vsrc.release();
+  g->piece_pairs = piece_pairs.as<uint64_t>(), piece_pairs.release();
   RgArgs<T> none{};
   SPAM_TRY(rg_dispatch<T>(g, &none, s, &g->grid));
+  if (g->grid == 0) return SPAM_OK;  // no kernel for these knobs / this device: *out stays null, the guard frees the plan
   guard.g = nullptr;
   *out = g;
   return SPAM_OK;
