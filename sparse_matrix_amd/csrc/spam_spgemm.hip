@@ -75,6 +75,11 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d, 64));
+  return v;
+}
 // the same sum through DPP moves (no LDS crossbar round trips); the total is returned in every lane
 __device__ __forceinline__ uint32_t wave_sum_dpp_u32(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
@@ -546,41 +551,110 @@ __global__ __launch_bounds__(TPB) void num_row_kernel(
 // of them, most of the entries) take one wavefront each, which finds the chunk boundaries among its lanes' entries.
 constexpr uint32_t BPOS_SHORT = 64;
 
-__global__ __launch_bounds__(256) void bpos_short_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
-                                                        uint32_t rows_b, uint32_t nchunks, int CW_SHIFT,
-                                                        uint32_t* __restrict__ bpos) {
+// (round 4) Two changes.  (1) The walk needs each row's next chunk number at every step; read from HBM that was one
+// dependent load per step and lane — 1.3 ms for a table whose 0.54 GB of stores take 0.15.  The chunk numbers of the 64
+// rows of a wavefront are therefore staged in LDS first (64 independent gathers per lane at most, stride 65 words per
+// lane: conflict-free when the cursors move together) and the walk reads them from there.  (2) The rows of more than
+// BPOS_SHORT entries used to fill their column of the table themselves, one 4-byte store per chunk into a line the
+// short rows' wavefront had left a hole in (1.35 ms: a read-modify-write of a line per store).  Now bpos_long_kernel
+// writes the boundaries of every long row into a compact row-major side array (one wavefront per row, coalesced) and
+// the walk kernel's lanes that hold a long row read their boundaries from there, so every store of the table is a
+// full 256-byte line of 64 consecutive rows.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v);
+constexpr uint32_t BPOS_SEG = 1024;  // entries of a long row one wavefront looks at (a hub row of 50 000 entries walked by ONE
+                                     // wavefront was the critical path of the whole table: 780 dependent round trips, 1.25 ms)
+struct BposItem {
+  uint32_t k, seg;
+};
+// One thread per row: long rows get a slot in the side array and one work item per BPOS_SEG entries.
+__global__ __launch_bounds__(256) void bpos_long_items_kernel(const uint64_t* __restrict__ b_rp, uint32_t rows_b,
+                                                             uint32_t* __restrict__ counters /* [0] long rows, [1] items */,
+                                                             uint32_t* __restrict__ lslot, BposItem* __restrict__ items) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= rows_b) return;
-  const uint64_t s = b_rp[k], e = b_rp[k + 1];
-  if (e - s > BPOS_SHORT) return;
-  uint64_t q = s;
-  uint32_t nc = q < e ? b_col[q] >> CW_SHIFT : 0xFFFFFFFFu;  // chunk of the entry at q
-  for (uint32_t j = 0; j <= nchunks; ++j) {
-    while (nc < j) {
-      ++q;
-      nc = q < e ? b_col[q] >> CW_SHIFT : 0xFFFFFFFFu;
-    }
-    bpos[(uint64_t)j * rows_b + k] = (uint32_t)q;
+  const int lane = threadIdx.x & 63;
+  uint64_t len = 0;
+  if (k < rows_b) len = b_rp[k + 1] - b_rp[k];
+  const bool is_long = len > BPOS_SHORT;
+  const uint32_t nseg = is_long ? (uint32_t)((len + BPOS_SEG - 1) / BPOS_SEG) : 0u;
+  // one atomic per wavefront and counter (40 000 long rows adding to two addresses one by one took 0.13 ms)
+  const uint64_t bal = __ballot(is_long);
+  if (!bal) return;
+  const uint32_t inc = wave_incl_scan_u32(nseg), tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+  uint32_t slot0 = 0, base0 = 0;
+  if (lane == 0) slot0 = atomicAdd(&counters[0], (uint32_t)__popcll(bal)), base0 = atomicAdd(&counters[1], tot);
+  slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0), base0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)base0);
+  if (!is_long) return;
+  lslot[k] = slot0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+  const uint32_t base = base0 + inc - nseg;
+  for (uint32_t i = 0; i < nseg; ++i) items[base + i] = BposItem{k, i};
+}
+// One wavefront per item: the chunk boundaries that fall into its segment of the row, written to the row's line of lb.
+__global__ __launch_bounds__(256) void bpos_long_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
+                                                       uint32_t nchunks, uint32_t lb_stride, int CW_SHIFT,
+                                                       const uint32_t* __restrict__ counters, const uint32_t* __restrict__ lslot,
+                                                       const BposItem* __restrict__ items, uint32_t* __restrict__ lb) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= counters[1]) return;
+  const BposItem it = items[w];
+  const uint64_t s = b_rp[it.k], e = b_rp[it.k + 1];
+  const uint64_t q0 = s + (uint64_t)it.seg * BPOS_SEG, q1 = q0 + BPOS_SEG < e ? q0 + BPOS_SEG : e;
+  uint32_t* out = lb + (uint64_t)lslot[it.k] * lb_stride;
+  for (uint64_t q = q0 + lane; q < q1; q += 64) {
+    const uint32_t cq = b_col[q] >> CW_SHIFT;
+    const uint32_t cp = (q == s) ? 0u : (b_col[q - 1] >> CW_SHIFT);
+    for (uint32_t j = cp + 1; j <= cq; ++j) out[j] = (uint32_t)q;
+  }
+  if (it.seg == 0 && lane == 0) out[0] = (uint32_t)s;
+  if (q1 == e) {  // (uniform) the chunks behind the row's last entry
+    const uint32_t cl = b_col[e - 1] >> CW_SHIFT;
+    for (uint32_t j = cl + 1 + lane; j <= nchunks; j += 64) out[j] = (uint32_t)e;
   }
 }
 
-__global__ __launch_bounds__(256) void bpos_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
-                                                  uint32_t rows_b, uint32_t nchunks, int CW_SHIFT,
-                                                  uint32_t* __restrict__ bpos) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t k = wave; k < rows_b; k += nwaves) {
-    const uint64_t s = b_rp[k], e = b_rp[k + 1];
-    if (e - s <= BPOS_SHORT) continue;  // bpos_short_kernel's
-    for (uint64_t q = s + lane; q < e; q += 64) {
-      const uint32_t cq = b_col[q] >> CW_SHIFT;
-      const uint32_t cp = (q == s) ? 0u : (b_col[q - 1] >> CW_SHIFT);
-      for (uint32_t j = cp + 1; j <= cq; ++j) bpos[(uint64_t)j * rows_b + k] = (uint32_t)q;
+__global__ __launch_bounds__(64) void bpos_walk_kernel(const uint64_t* __restrict__ b_rp, const uint32_t* __restrict__ b_col,
+                                                      uint32_t rows_b, uint32_t nchunks, uint32_t lb_stride, int CW_SHIFT,
+                                                      const uint32_t* __restrict__ lslot, const uint32_t* __restrict__ lb,
+                                                      uint32_t* __restrict__ bpos) {
+  __shared__ uint32_t st[64 * (BPOS_SHORT + 1)];
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t s = 0, e = 0;
+  if (k < rows_b) s = b_rp[k], e = b_rp[k + 1];
+  const bool in = k < rows_b, is_long = in && e - s > BPOS_SHORT;
+  const uint32_t len = in && !is_long ? (uint32_t)(e - s) : 0u;
+  // a long row's boundaries come from its line of lb, four at a time (16 bytes per lane), read one group ahead
+  const u32x4* mine_lb = reinterpret_cast<const u32x4*>(lb + (is_long ? (uint64_t)lslot[k] * lb_stride : 0ull));
+  uint32_t* my = st + threadIdx.x * (BPOS_SHORT + 1);
+  const uint32_t maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(len));
+  for (uint32_t i0 = 0; i0 < maxlen; i0 += 8) {
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = i0 + u < len ? b_col[s + i0 + u] >> CW_SHIFT : 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < len) my[i0 + u] = c[u];
+  }
+  // (each lane reads back only what it wrote itself: no barrier)
+  uint32_t cur = 0;
+  uint32_t nc = cur < len ? my[cur] : 0xFFFFFFFFu;  // chunk of the entry at the cursor
+  u32x4 nxt = {0u, 0u, 0u, 0u};
+  if (is_long) nxt = mine_lb[0];
+  for (uint32_t j0 = 0; j0 <= nchunks; j0 += 4) {
+    const u32x4 lbv = nxt;
+    if (is_long && j0 + 4 <= nchunks) nxt = mine_lb[(j0 >> 2) + 1];  // (lb lines are padded to a multiple of 4 words)
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t j = j0 + u;
+      if (j > nchunks) break;
+      while (nc < j) {
+        ++cur;
+        nc = cur < len ? my[cur] : 0xFFFFFFFFu;
+      }
+      uint32_t v = (uint32_t)(s + cur);
+      if (is_long) v = lbv[u];
+      if (in) bpos[(uint64_t)j * rows_b + k] = v;
     }
-    if (lane == 0) bpos[k] = (uint32_t)s;
-    const uint32_t cl = (e > s) ? (b_col[e - 1] >> CW_SHIFT) : 0u;  // (the chunks behind the row's last entry: all lanes)
-    for (uint32_t j = cl + 1 + lane; j <= nchunks; j += 64) bpos[(uint64_t)j * rows_b + k] = (uint32_t)e;
   }
 }
 
@@ -1228,6 +1302,8 @@ __global__ __launch_bounds__(TPB, WAVES_PER_SIMD) void sym_heavy_kernel(const ui
   const uint32_t ch_per_win = (1u << WIN_SHIFT) >> cw_shift;    // numeric chunks per window
   // the first n_giant rows of the list (the heaviest: a (row, window) item of theirs would keep one workgroup busy for
   // milliseconds while the rest of the chip has run dry) are cut into sub-windows of sub_chunks chunks instead
+  // (round 4 measured sub-windows that double inside every window — 24 items per giant row instead of 128 — against
+  // these uniform ones on the 8 rank blocks of scale 20: symbolic phase 4.1 against 4.0 ms per block, no difference)
   const uint32_t nsub = (nchunks + sub_chunks - 1) / sub_chunks;
   const uint32_t n_giant_items = n_giant * nsub;
   const uint32_t n_items = n_giant_items + (n_rows - n_giant) * nwin;  // (the host checks that this fits 32 bits)
@@ -2473,12 +2549,26 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     p->use_bpos = p->nchunks > 1;
     if (p->use_bpos) {
       SPAM_TRY(p->bpos.alloc((uint64_t)(p->nchunks + 1) * b->rows * 4));
-      unsigned grid = (unsigned)std::min<uint64_t>((b->rows + 3) / 4, 16384);
-      bpos_short_kernel<<<(unsigned)((b->rows + 255) / 256), 256, 0, s>>>(b->row_ptr, p->b_col, (uint32_t)b->rows, p->nchunks,
-                                                                          p->cw_shift, p->bpos.as<uint32_t>());
+      // side array of the long rows' boundaries: a row of more than BPOS_SHORT entries holds at least BPOS_SHORT + 1
+      DevBuf lslot, lb, nlong, litems;
+      const uint64_t max_long = b->nnz / (BPOS_SHORT + 1) + 1, max_items = b->nnz / BPOS_SEG + max_long;
+      const uint32_t lb_stride = (p->nchunks + 1 + 3) & ~3u;
+      SPAM_TRY(lslot.alloc(b->rows * 4));
+      SPAM_TRY(lb.alloc(max_long * lb_stride * 4 + 16));
+      SPAM_TRY(litems.alloc(max_items * sizeof(BposItem)));
+      SPAM_TRY(nlong.alloc(16));
+      SPAM_HIP_TRY(hipMemsetAsync(nlong.p, 0, 16, s));
+      bpos_long_items_kernel<<<(unsigned)((b->rows + 255) / 256), 256, 0, s>>>(b->row_ptr, (uint32_t)b->rows, nlong.as<uint32_t>(),
+                                                                               lslot.as<uint32_t>(), litems.as<BposItem>());
       SPAM_CHECK_LAUNCH();
-      bpos_kernel<<<grid, 256, 0, s>>>(b->row_ptr, p->b_col, (uint32_t)b->rows, p->nchunks, p->cw_shift, p->bpos.as<uint32_t>());
+      bpos_long_kernel<<<(unsigned)((max_items + 3) / 4), 256, 0, s>>>(b->row_ptr, p->b_col, p->nchunks, lb_stride, p->cw_shift,
+                                                                      nlong.as<uint32_t>(), lslot.as<uint32_t>(), litems.as<BposItem>(),
+                                                                      lb.as<uint32_t>());
       SPAM_CHECK_LAUNCH();
+      bpos_walk_kernel<<<(unsigned)((b->rows + 63) / 64), 64, 0, s>>>(b->row_ptr, p->b_col, (uint32_t)b->rows, p->nchunks, lb_stride,
+                                                                      p->cw_shift, lslot.as<uint32_t>(), lb.as<uint32_t>(), p->bpos.as<uint32_t>());
+      SPAM_CHECK_LAUNCH();
+      // (lslot / lb go back to the allocator here; later users are queued on the same stream behind the walk kernel)
     }
     SPAM_TRY(p->hcnt.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
     SPAM_TRY(p->hoff.alloc((uint64_t)p->n_heavy * p->nchunks * 4));
@@ -2504,6 +2594,10 @@ static int symbolic_impl(const spam_csr* a, const spam_csr* b, spam_spgemm_plan*
     uint32_t n_giant = 0;
     int giant_log2 = 22;
     while (giant_log2 < 62 && (1ull << giant_log2) < st.flops_f / 1024) ++giant_log2;
+    {
+      const char* gs = getenv("SPAM_SYM_GIANT_SHIFT");  // A/B runs: move the threshold by powers of two
+      if (gs) giant_log2 = std::max(12, std::min(62, giant_log2 + atoi(gs)));
+    }
     const uint32_t sub_chunks = std::max<uint32_t>(1u, ((1u << win_shift) >> p->cw_shift) / 32u);
     if (p->use_bpos) {
       uint32_t ends[64];
