@@ -407,7 +407,7 @@ def main():
             B, received = comm.allgather_csr(shard, offs0)  # values still in flight: only the numeric phase waits
             xfer.update({"bytes_received": received, "mode": "C ABI: grouped ncclSend/ncclRecv per peer (libspam_hip_rccl.so)",
                          "flop_count": "sharded over the ranks' initial row blocks, per-row counts all-gathered (8 B/row)"})
-            C, st, (mylo, myhi) = comm.rank_step(B, B, offs0, spdist.ROW_OVERHEAD_PRODUCTS, sort_rows)
+            C, st, (mylo, myhi) = comm.rank_step(B, B, offs0, spdist.ROW_OVERHEAD_AUTO, sort_rows)
             if C is None:
                 return None, None
             C._keep = (C._keep, B)
@@ -424,7 +424,7 @@ def main():
             B = DeviceCsr.from_torch(n, n, g.row_ptr, g.col_idx, g.vals, True)
             if world > 1:
                 # rows_to_threads' flop count and partition rule (mul_hash.rs:39-62) on F + a per-row cost, on the device
-                offs = B.balanced_row_blocks(B, world, spdist.ROW_OVERHEAD_PRODUCTS)
+                offs = B.balanced_row_blocks(B, world, spdist.ROW_OVERHEAD_AUTO)
                 mylo, myhi = int(offs[rank]), int(offs[rank + 1])
                 if myhi <= mylo:
                     g.wait_values()

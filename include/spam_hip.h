@@ -222,10 +222,17 @@ int spam_spgemm_dev(const spam_csr* a, const spam_csr* b, int sort_rows, spam_cs
  * all-gather of the ranks' row shards, which is the HOST's step: exchange the three arrays of spam_csr_device_ptrs
  * with RCCL — INTEGRATION.md shows the grouped ncclSend / ncclRecv sequence — and wrap the result with
  * spam_csr_from_device).  *c_block = the block of C (NULL when the block has no rows); C stays row-sharded.
- * row_overhead: 4000 measured on MI355X (spam_rows_to_parts_weighted). */
+ * row_overhead: SPAM_ROW_OVERHEAD_AUTO (below) unless the caller knows better. */
 int spam_spgemm_rank_step(const spam_csr* a_full, const spam_csr* b_full, uint64_t rank, uint64_t world,
                           uint64_t row_overhead, int sort_rows, spam_csr** c_block, uint64_t* row_lo, uint64_t* row_hi,
                           spam_spgemm_stats* stats);
+
+/* row_overhead = SPAM_ROW_OVERHEAD_AUTO lets the library pick the per-row term from the width of B (32 products per
+ * 8192-column chunk of B: a non-empty row of the heavy path costs work per chunk it is cut along; measured on MI355X at
+ * R-MAT scale 20 and 22, tools/partition_balance.py).  0 is the reference's rule on F alone.  spam_row_overhead_auto
+ * returns the value AUTO stands for. */
+#define SPAM_ROW_OVERHEAD_AUTO 0xFFFFFFFFFFFFFFFFull
+uint64_t spam_row_overhead_auto(const spam_csr* b);
 
 /* rows_to_threads (mul_hash.rs:38-64) with tnum = nparts: per-row intermediate-product counts and the
  * flop-balanced contiguous row ranges rows_offset[0..nparts].  row_flops_out may be NULL. */

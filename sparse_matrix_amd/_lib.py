@@ -94,6 +94,7 @@ SYMBOLS = {
                                         C.POINTER(SpgemmStats)]),
     "spam_rows_to_parts": (C.c_int, [_P, _P, _U64, _P, _P]),
     "spam_rows_to_parts_weighted": (C.c_int, [_P, _P, _U64, _U64, _P]),
+    "spam_row_overhead_auto": (_U64, [_P]),
     "spam_row_flops_dev": (C.c_int, [_P, _P, _U64, _U64, _P]),
     "spam_rows_to_parts_from_flops_dev": (C.c_int, [_P, _U64, _U64, _U64, _P]),
 }
@@ -112,6 +113,7 @@ SYMBOLS_RCCL = {
                                              C.POINTER(SpgemmStats)]),
 }
 RCCL_ID_BYTES = 128
+ROW_OVERHEAD_AUTO = 0xFFFFFFFFFFFFFFFF  # SPAM_ROW_OVERHEAD_AUTO: per-row partition term from the width of B
 LIB_RCCL_PATH = os.path.join(_HERE, "libspam_hip_rccl.so")
 
 _lib = None

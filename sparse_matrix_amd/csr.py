@@ -214,7 +214,7 @@ class DeviceCsr:
             L.spam_spgemm_plan_free(plan)
         return DeviceCsr(h), st.asdict()
 
-    def rank_step(self, rhs: "DeviceCsr", rank: int, world: int, row_overhead: int = 4000, sort_rows=False):
+    def rank_step(self, rhs: "DeviceCsr", rank: int, world: int, row_overhead: int = _lib.ROW_OVERHEAD_AUTO, sort_rows=False):
         """This rank's block of C = self * rhs on `world` GPUs (spam_spgemm_rank_step): returns (C block or None,
         stats dict, (row_lo, row_hi))."""
         h = C.c_void_p()
@@ -231,7 +231,7 @@ class DeviceCsr:
         check(_lib.load().spam_rows_to_parts(self._h, rhs._h, nparts, _vp(flops), _vp(offs)))
         return flops, offs
 
-    def balanced_row_blocks(self, rhs: "DeviceCsr", nparts: int, row_overhead: int = 4000) -> list:
+    def balanced_row_blocks(self, rhs: "DeviceCsr", nparts: int, row_overhead: int = _lib.ROW_OVERHEAD_AUTO) -> list:
         """Contiguous row blocks balanced by F + row_overhead per non-empty row, computed on the device."""
         offs = np.empty(nparts + 1, dtype=np.uint64)
         check(_lib.load().spam_rows_to_parts_weighted(self._h, rhs._h, nparts, row_overhead, _vp(offs)))

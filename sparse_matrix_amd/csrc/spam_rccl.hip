@@ -308,6 +308,7 @@ int spam_spgemm_rank_step_rccl(spam_comm* c, const spam_csr* a_full, const spam_
   SPAM_TRY(order_after_library(c));
   SPAM_TRY(allgatherv_bytes(c, mine.p, flops.p, start));
   SPAM_TRY(library_after_exchange(c));
+  if (row_overhead == SPAM_ROW_OVERHEAD_AUTO) row_overhead = spam_row_overhead_auto(b_full);
   // (3) the partition rule on the same vector on every rank (mul_hash.rs:51-62, tnum = world)
   std::vector<uint64_t> offs(W + 1);
   SPAM_TRY(spam_rows_to_parts_from_flops_dev(flops.as<uint64_t>(), rows, (uint64_t)W, row_overhead, offs.data()));

@@ -2984,6 +2984,7 @@ static int rows_to_parts_impl(const spam_csr* a, const spam_csr* b, uint64_t npa
   clear_error();
   if (!rows_offset_out || nparts == 0) return set_error(SPAM_E_INVALID, "bad nparts / NULL output");
   SPAM_TRY(check_pair(a, b));
+  if (row_overhead == SPAM_ROW_OVERHEAD_AUTO) row_overhead = spam_row_overhead_auto(b);
   hipStream_t s = stream();
   DevBuf flops, total;
   SPAM_TRY(flops.alloc(a->rows * 8));
@@ -2998,6 +2999,17 @@ static int rows_to_parts_impl(const spam_csr* a, const spam_csr* b, uint64_t npa
   // (lib.rs:267-274) from wrapping (rows < 2^32, so F < 2^63 leaves room for any sane overhead)
   if (htot[0] >= (1ull << 63)) return set_error(SPAM_E_OVERFLOW, "partition cost would overflow the u64 prefix sums (lib.rs:270)");
   return parts_from_flops(flops.as<uint64_t>(), a->rows, nparts, row_overhead, rows_offset_out, s);
+}
+
+// The per-row term of the partition cost, in products.  A non-empty row of the heavy path costs work in proportion to
+// the number of column chunks it is cut along (B-split lookups, work items, drain), so the term grows with the width
+// of B: 32 products per 8192-column chunk — 4000 at scale 20 (128 chunks), where 0 / 2300 / 4000 / 6000 gave mean / max
+// block times of 0.91 / 0.94 / 0.96 / 0.95, and 16 000 at scale 22 (512 chunks), where 4000 / 8000 / 12 000 / 16 000 gave
+// 0.81 / 0.85 / 0.89 / see profiles/r04_partition_balance.txt.
+uint64_t spam_row_overhead_auto(const spam_csr* b) {
+  if (!b) return 4000;
+  const uint64_t chunks = (b->cols + (1ull << CW_SHIFT_512) - 1) >> CW_SHIFT_512;
+  return std::max<uint64_t>(1000, std::min<uint64_t>(32 * chunks, 1ull << 20));
 }
 
 int spam_row_flops_dev(const spam_csr* a, const spam_csr* b, uint64_t row_lo, uint64_t row_hi, uint64_t* d_flops_out) {

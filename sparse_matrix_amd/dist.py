@@ -164,7 +164,9 @@ def rows_to_parts_host(row_flops: torch.Tensor, nparts: int) -> list[int]:
     return offs
 
 
-ROW_OVERHEAD_PRODUCTS = 4000  # measured on MI355X (scale-20 A*A, round-2 kernels): a non-empty row costs about as much as 4000 products
+ROW_OVERHEAD_PRODUCTS = 4000  # measured on MI355X (scale-20 A*A): a non-empty row costs about as much as 4000 products — at 128
+                              # column chunks of B; the library scales it with the width of B (SPAM_ROW_OVERHEAD_AUTO)
+ROW_OVERHEAD_AUTO = 0xFFFFFFFFFFFFFFFF
 
 
 def balanced_row_blocks(row_flops, nparts: int, row_overhead: int = ROW_OVERHEAD_PRODUCTS) -> list[int]:
@@ -244,7 +246,7 @@ class RcclComm:
                                                        C.c_void_p(out.data_ptr())))
         return out
 
-    def rank_step(self, a_full, b_full, count_offsets=None, row_overhead: int = ROW_OVERHEAD_PRODUCTS, sort_rows=False):
+    def rank_step(self, a_full, b_full, count_offsets=None, row_overhead: int = ROW_OVERHEAD_AUTO, sort_rows=False):
         """spam_spgemm_rank_step_rccl: sharded flop count + all-gather of the counts + partition + this rank's block of
         C.  Returns (C block or None, stats dict, (row_lo, row_hi))."""
         from ._lib import SpgemmStats

@@ -37,7 +37,7 @@ for dtype in (torch.float64, torch.float32, torch.int64):
     assert received == 0  # a world of one receives nothing from OTHER ranks; the self send / recv still ran
     # structure is usable at once: partition + symbolic phase read row_ptr / col_idx only
     flops, offs = B.rows_to_parts(B, 4)
-    Cb, st, (lo, hi) = comm.rank_step(B, B, None, 4000, sort_rows=True)
+    Cb, st, (lo, hi) = comm.rank_step(B, B, None, sort_rows=True)  # row overhead: SPAM_ROW_OVERHEAD_AUTO
     assert (lo, hi) == (0, n) and st["rows"] == n
     go, gi, gv = B.download()          # waits for the values on the device
     ho, hi_, hv = shard.download()

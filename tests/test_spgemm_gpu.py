@@ -306,7 +306,9 @@ def test_scale22_rank_blocks_cfg4(spam, oracle):
     A = synth.rmat(22, dtype=torch.float64, device=dev)
     n = A.rows
     dB = DeviceCsr.from_torch(n, n, A.row_ptr, A.col_idx, A.vals, True)
-    offs = dB.balanced_row_blocks(dB, 8, 4000)
+    offs = dB.balanced_row_blocks(dB, 8)  # SPAM_ROW_OVERHEAD_AUTO: 32 products per 8192-column chunk of B = 16 384 at scale 22
+    from sparse_matrix_amd import _lib as _l
+    assert int(_l.load().spam_row_overhead_auto(dB._h)) == 32 * 512
     assert offs[0] == 0 and offs[-1] == n and all(b > a for a, b in zip(offs[:-1], offs[1:]))
     b_host = A.cpu_numpy()
     x = synth.dense_vector(n, dtype=torch.float64, device=dev)

@@ -16,21 +16,21 @@ A = synth.rmat(scale, dtype=torch.float64, device=dev)
 B = DeviceCsr.from_torch(A.rows, A.cols, A.row_ptr, A.col_idx, A.vals, True)
 from sparse_matrix_amd import dist as spdist
 flops, offs = B.rows_to_parts(B, P)
+RO = int(os.environ["ROW_OVERHEAD"]) if "ROW_OVERHEAD" in os.environ else int(_lib.load().spam_row_overhead_auto(B._h))
+print("row overhead", RO, "products per non-empty row", "(library default for this B)" if "ROW_OVERHEAD" not in os.environ else "(forced)")
 if os.environ.get("WEIGHTED", "1") == "1":
-    offs = np.array(spdist.balanced_row_blocks(flops.astype(np.int64), P, int(os.environ.get("ROW_OVERHEAD", spdist.ROW_OVERHEAD_PRODUCTS))))
+    offs = np.array(spdist.balanced_row_blocks(flops.astype(np.int64), P, RO))
 print("offsets", offs.tolist())
 tot = []
-for rep in range(2):
-    times = []
-    for r in range(P):
-        lo, hi = int(offs[r]), int(offs[r + 1])
-        blk = B.row_block(lo, hi)
+for r in range(P):  # block-major, the last of three runs: the first sizes the library's allocator for this block's C
+    lo, hi = int(offs[r]), int(offs[r + 1])
+    blk = B.row_block(lo, hi)
+    for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         C, st = blk.spgemm(B, sort_rows=False)
         torch.cuda.synchronize(); t = time.perf_counter() - t0
-        times.append((t * 1e3, st["flops_f"], st["nnz_c"], hi - lo, st["ms_symbolic"], st["ms_numeric"]))
         C.free()
-    tot = times
+    tot.append((t * 1e3, st["flops_f"], st["nnz_c"], hi - lo, st["ms_symbolic"], st["ms_numeric"]))
 # the product in one piece, same process (t1 of the strong-scaling estimate), and the per-rank fixed work of the
 # multi-GPU step (spam_spgemm_rank_step_rccl): flop count of 1/P of the rows + partition of the all-gathered counts
 t1s = []
@@ -51,7 +51,7 @@ fixed = []
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     _lib.check(L.spam_row_flops_dev(B._h, B._h, 0, n // P, ctypes.c_void_p(dfl.data_ptr())))
-    _lib.check(L.spam_rows_to_parts_from_flops_dev(ctypes.c_void_p(dfl.data_ptr()), n, P, int(os.environ.get("ROW_OVERHEAD", spdist.ROW_OVERHEAD_PRODUCTS)), offs_out))
+    _lib.check(L.spam_rows_to_parts_from_flops_dev(ctypes.c_void_p(dfl.data_ptr()), n, P, RO, offs_out))
     torch.cuda.synchronize(); fixed.append((time.perf_counter() - t0) * 1e3)
 fixed_ms = float(np.median(fixed[1:]))
 for r, (t, f, n, rows, ms_s, ms_n) in enumerate(tot):
