@@ -157,7 +157,10 @@ int spam_spmv_dev(const spam_csr* a, const void* d_x, void* d_y);
 int spam_spmv_prepare(spam_csr* a, const void* d_x);
 /* The SpMV plan of a prepared handle may hold private copies of the matrix VALUES (the XCD-sliced structure stores the
  * long rows again, slab by slab).  After updating vals in place — allowed for arrays wrapped by spam_csr_from_device /
- * from_sorted_coo — call this to gather them again (asynchronous, a few ms for 160 M entries; no new analysis).  The
+ * from_sorted_coo — call this to gather them again (no new analysis, no new timing of the paths).  A row-group plan
+ * keeps no map from its value positions back to the matrix (4 bytes per entry) unless SPAM_SPMV_RG_VSRC=1: the FIRST
+ * call builds that plan again with the map (once: what spam_spmv_prepare spent on it, host-synchronised), later calls
+ * are asynchronous and take a few ms for 160 M entries.  The
  * STRUCTURE (row_ptr, col_idx) of a handle must never change: wrap a new handle instead. */
 int spam_csr_values_changed(spam_csr* a);
 /* What the SpMV analysis of this matrix decided (valid after spam_spmv_prepare): number of columns in the

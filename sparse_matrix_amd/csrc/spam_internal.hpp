@@ -178,6 +178,8 @@ struct RgKnobs {
   int fold_short = 1; // SPAM_SPMV_RG_SHORT  the short rows as blocks of the same kernel (0: spmv_short_rows_kernel)
   int prof = 0;       // SPAM_SPMV_PROF = 3   per-block phase timers, printed by every SpMV (diagnostics)
   int order_min = 32; // SPAM_SPMV_RG_ORDER  rows with fewer entries are ranked in row order (coalesced y writes), longer ones by length
+  int keep_vsrc = 0;  // SPAM_SPMV_RG_VSRC   1: build the value-source map (4 bytes per padded entry) at prepare; 0: on the first
+                      //                     spam_csr_values_changed (most matrices never change their values)
   int fmt = 2;        // SPAM_SPMV_RG_FMT    packed entry words a block may use: 0 none (32-bit words), 1 up to 24-bit, 2 up to 16-bit
 };
 struct RgPlan {
@@ -197,7 +199,8 @@ struct RgPlan {
   void* tiles = nullptr;            // RgTile[ntiles]: 64 rank slots of one group each
   uint64_t* grp_cp = nullptr;       // u64[ng][NPART]: first pair of every (group, part) block in cp
   void* cp = nullptr;               // T[npairs]: the pair sums of one SpMV
-  uint32_t* vsrc = nullptr;         // u32[padded]: source entry of every value position (spam_csr_values_changed)
+  uint32_t* vsrc = nullptr;         // u32[padded]: source entry of every value position (spam_csr_values_changed); null until
+                                    // the first such call unless SPAM_SPMV_RG_VSRC=1 (0.69 GB for the bench matrix)
   uint64_t* piece_pairs = nullptr;  // u64[n_piece_pairs]: pairs of the blocks run in pieces (their sums meet by atomic adds):
   uint32_t n_piece_pairs = 0;       // set to zero by the first kernel of every product
 };

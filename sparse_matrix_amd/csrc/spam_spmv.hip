@@ -737,6 +737,7 @@ static SpmvKnobs read_knobs() {
   k.rgk.fold_short = env_int("SPAM_SPMV_RG_SHORT", 1);
   k.rgk.order_min = env_int("SPAM_SPMV_RG_ORDER", k.rgk.order_min);
   k.rgk.fmt = env_int("SPAM_SPMV_RG_FMT", k.rgk.fmt);
+  k.rgk.keep_vsrc = env_int("SPAM_SPMV_RG_VSRC", k.rgk.keep_vsrc);
   k.rgk.prof = k.prof;
 
   return k;
@@ -1148,6 +1149,18 @@ __global__ void sliced_assign_kernel(const uint32_t* __restrict__ f0, const uint
 }
 // include_empty: rows without entries join the short rows (as rows of zero entries): every row of y is then written by
 // the kernel that owns it — the reduce (sliced rows) or a short-row block — and the zero-fill of y is not needed.
+// code / slab of every column back from dest (the row-group form keeps only dest between analyses)
+__global__ void sliced_code_from_dest_kernel(const uint32_t* __restrict__ dest, uint32_t cols, uint32_t S,
+                                             uint32_t* __restrict__ code, uint8_t* __restrict__ slab) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cols) return;
+  const uint32_t d = dest[i];
+  if (d == NO_DEST) {
+    code[i] = (uint32_t)i, slab[i] = (uint8_t)NSLAB;
+  } else {
+    code[i] = d % S, slab[i] = (uint8_t)(d / S);
+  }
+}
 __global__ void sliced_row_flags_kernel(const uint32_t* __restrict__ row_ptr, uint32_t rows, uint32_t long_min,
                                         int include_empty, uint32_t* __restrict__ is_long,
                                         uint32_t* __restrict__ short_len, uint32_t* __restrict__ is_short) {
@@ -1597,6 +1610,31 @@ static int sliced_refresh_values(const spam_csr* a, SlicedPlan* q, hipStream_t s
     sliced_residual_fill_kernel<T, true><<<gr, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->long_min, q->res32, rows,
                                                             q->residual->col_idx, (T*)q->residual->vals);
     SPAM_CHECK_LAUNCH();
+    if (!q->rg->vsrc) {
+      // The plan was built without the value-source map (4 bytes per padded entry: 0.69 GB for the bench matrix, and most
+      // matrices never change their values).  First change: build the row-group plan again, with the map — same
+      // inputs, same layout, and its stream already holds the new values; later changes take the short way below.
+      RgKnobs kn = a->spmv_plan ? a->spmv_plan->knobs.rgk : RgKnobs();
+      kn.keep_vsrc = 1, kn.prof = 0;
+      SPAM_HIP_TRY(hipStreamSynchronize(s));  // products queued on the old plan
+      RgPlan* fresh = nullptr;
+      DevBuf code, slab;  // (not kept by a row-group plan: both follow from dest)
+      const uint32_t cols = (uint32_t)a->cols;
+      SPAM_TRY(code.alloc((uint64_t)cols * 4));
+      SPAM_TRY(slab.alloc((uint64_t)cols));
+      sliced_code_from_dest_kernel<<<(unsigned)(((uint64_t)cols + 255) / 256), 256, 0, s>>>(q->dest, cols, q->S, code.as<uint32_t>(),
+                                                                                             slab.as<uint8_t>());
+      SPAM_CHECK_LAUNCH();
+      SPAM_TRY(rg_build<T>(a, slab.as<uint8_t>(), code.as<uint32_t>(), q->long_rows, q->nl, q->S, q->residual, q->ns, kn, s, &fresh));
+      SPAM_HIP_TRY(hipStreamSynchronize(s));
+      if (!fresh || fresh->npairs != q->rg->npairs || fresh->ntiles != q->rg->ntiles) {
+        if (fresh) rg_plan_free(fresh);
+        return set_error(SPAM_E_INVALID, "rebuilding the row-group plan for spam_csr_values_changed gave another layout");
+      }
+      rg_plan_free(q->rg);
+      q->rg = fresh;
+      return SPAM_OK;
+    }
     return rg_refresh_values<T>(a, q->residual, q->rg, s);  // (reads the residual's refreshed values)
   } else if (q->nl) {
     sliced_fill_kernel<T, true><<<gw, 256, 0, s>>>(a->row_ptr32, a->col_idx, (const T*)a->vals, q->code, q->slab, q->long_rows,
@@ -1977,7 +2015,7 @@ int spam_spmv_rg_info(const spam_csr* a, int* active, uint64_t* row_groups, uint
   if (accumulators) *accumulators = g ? g->naccs : 0;
   if (stream_bytes) *stream_bytes = g ? g->stream_bytes : 0;
   if (plan_bytes)
-    *plan_bytes = g ? g->stream_bytes + g->padded * 4 + ((uint64_t)g->ng * NPART + g->ngs + 1) * 48 + (uint64_t)g->ng * NPART * 8 +
+    *plan_bytes = g ? g->stream_bytes + (g->vsrc ? g->padded * 4 : 0) + ((uint64_t)g->ng * NPART + g->ngs + 1) * 48 + (uint64_t)g->ng * NPART * 8 +
                             (uint64_t)g->ntiles * (24 + 64 * 6) + g->npairs * 8 + (g->naccs - g->npairs) * 4
                       : 0;
   return SPAM_OK;

@@ -650,7 +650,7 @@ __global__ void rg_fill_kernel(const uint64_t* __restrict__ keys, const uint32_t
     if (real) {
       const uint32_t vs = rg_val_slot<T>(lane, k);
       reinterpret_cast<T*>(c + voff)[vs] = v;
-      vsrc[pe[b] + (chunk << 8) + vs] = src;
+      if (vsrc) vsrc[pe[b] + (chunk << 8) + vs] = src;
     }
   };
   uint64_t pos = j - sb;
@@ -1142,7 +1142,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_HIP_TRY(hipMemcpyAsync(tiles.p, h_tiles.data(), (uint64_t)ntiles * sizeof(RgTile), hipMemcpyHostToDevice, s));  // (with the clear flags)
   SPAM_TRY(pe.alloc(((uint64_t)nb + 1) * 8));
   SPAM_TRY(stream.alloc(g->stream_bytes + 16));
-  SPAM_TRY(vsrc.alloc(g->padded * 4 + 16));
+  if (kn.keep_vsrc) SPAM_TRY(vsrc.alloc(g->padded * 4 + 16));
   SPAM_TRY(sub_head.alloc(h_sub_head.size() * 4 + 4));
   SPAM_TRY(grp_cp.alloc((uint64_t)ng * SPMV_NPART * 8));
   SPAM_TRY(cp.alloc((npairs + 2) * sizeof(T)));
@@ -1164,7 +1164,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
     SPAM_TRY(scan_u32_to_u64(padv.as<uint32_t>(), n_all, pad_before.as<uint64_t>(), ptmp.p, s));
   }
   SPAM_HIP_TRY(hipMemsetAsync(stream.p, 0, g->stream_bytes + 16, s));     // padding values are zero
-  SPAM_HIP_TRY(hipMemsetAsync(vsrc.p, 0xFF, g->padded * 4 + 16, s));      // ... and have no source (RG_NONE)
+  if (vsrc.p) SPAM_HIP_TRY(hipMemsetAsync(vsrc.p, 0xFF, g->padded * 4 + 16, s));  // ... and have no source (RG_NONE)
   rg_fill_kernel<T><<<(unsigned)((n_all + 255) / 256), 256, 0, s>>>(
       keys_out.as<uint64_t>(), src_out.as<uint32_t>(), start.as<uint64_t>(), pe.as<uint64_t>(),
       any_packed ? pad_before.as<uint64_t>() : nullptr, blk.as<RgBlk>(), first_wide, first_short, (uint32_t)abits,
@@ -1182,7 +1182,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   g->tiles = tiles.release();
   g->grp_cp = grp_cp.as<uint64_t>(), grp_cp.release();
   g->cp = cp.release();
-  g->vsrc = vsrc.as<uint32_t>(), vsrc.release();
+  g->vsrc = vsrc.p ? vsrc.as<uint32_t>() : nullptr, vsrc.release();
   g->piece_pairs = piece_pairs.as<uint64_t>(), piece_pairs.release();
   RgArgs<T> none{};
   SPAM_TRY(rg_dispatch<T>(g, &none, s, &g->grid));
@@ -1247,6 +1247,7 @@ int rg_run(const RgPlan* g, const T* xh, uint32_t S, const T* x, uint32_t* queue
 template <class T>
 int rg_refresh_values(const spam_csr* a, const spam_csr* res, RgPlan* g, hipStream_t s) {
   if (g->padded == 0) return SPAM_OK;
+  if (!g->vsrc) return set_error(SPAM_E_INVALID, "row-group plan without value-source map (the caller rebuilds it)");
   rg_refresh_kernel<T><<<(unsigned)((g->padded + 255) / 256), 256, 0, s>>>(
       g->pe, (const RgBlk*)g->blk, g->ng * SPMV_NPART + g->ngs, g->ng * SPMV_NSLAB, g->ng * SPMV_NPART, g->vsrc,
       (const T*)a->vals, g->ngs ? (const T*)res->vals : nullptr, g->stream, g->padded);
