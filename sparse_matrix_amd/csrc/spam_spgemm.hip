@@ -1141,6 +1141,9 @@ __device__ __forceinline__ void wave_products(uint32_t lo, uint32_t len, T av, b
         maxspan = a1 - a0 > maxspan ? a1 - a0 : maxspan;
       }
     }
+#ifdef SPAM_ABLATE_SEARCH  // (timing experiments only: results are wrong)
+    maxspan = 0;
+#endif
     for (uint32_t span = maxspan; span != 0; span >>= 1) {  // uniform trip count
       uint32_t v[WAVE_U], mid[WAVE_U];
 #pragma unroll
@@ -1732,7 +1735,11 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
       for (uint32_t i0 = wave * wpw; i0 < wend; i0 += 64) {
         const uint32_t i = i0 + lane;
         const RankWord wn = word_at(i + 64);  // the next step's word: its LDS round trip overlaps this step's stores
+#ifdef SPAM_ABLATE_DRAINCOLS  // (timing experiments only: results are wrong)
+        if (false) {
+#else
         if (w.bits) {
+#endif
           uint32_t bits = w.bits;
           uint64_t o = out + w.prefix;
           const uint32_t cbase = c0 + (i << 5);

@@ -7,5 +7,5 @@ NAME=$1; FLAGS=$2
 HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -ffp-contract=off -Wall -Wno-unused-function"
 make -s
 for f in spam_spgemm spam_spmv; do /opt/rocm/bin/hipcc $HIPFLAGS $FLAGS -c $f.hip -o /tmp/${f}_$NAME.o & done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libspam_hip_$NAME.so spam_core.o spam_scan.o /tmp/spam_spmv_$NAME.o /tmp/spam_spgemm_$NAME.o spam_ewise.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libspam_hip_$NAME.so spam_core.o spam_scan.o /tmp/spam_spmv_$NAME.o spam_spmv_rg.o /tmp/spam_spgemm_$NAME.o spam_ewise.o
 echo built ../libspam_hip_$NAME.so
