@@ -1741,9 +1741,9 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
         if (w.bits) {
 #endif
           uint32_t bits = w.bits;
-          uint64_t o = out + w.prefix;
           const uint32_t cbase = c0 + (i << 5);
-          while (bits) {
+          uint64_t o = out + w.prefix;
+          while (bits) {  // (round 4: two set bits per trip with 32-bit offsets from a uniform base measured 1.5 ms slower)
             c_col[o++] = cbase + (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1;
           }
