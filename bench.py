@@ -410,11 +410,26 @@ def main():
         # around and provides the bench's barrier).  SPAM_EXCHANGE=torch selects the torch.distributed all_to_all of
         # dist.py instead (and is what a gloo rehearsal on one GPU uses: RCCL refuses two ranks on one device).
         use_cabi = world > 1 and backend == "nccl" and os.environ.get("SPAM_EXCHANGE", "cabi") == "cabi"
-        if use_cabi:
-            if comm_box[0] is None:
+        if use_cabi and comm_box[0] is None:
+            # every rank must agree on the path: a rank whose communicator cannot be made (library missing, RCCL refusing the
+            # topology) would otherwise leave the others waiting in a collective
+            err = None
+            try:
                 comm_box[0] = spdist.RcclComm.from_torch_dist(dist, rank, world)
+            except Exception as ex:  # noqa: BLE001
+                err = f"{type(ex).__name__}: {ex}"
+            okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                if comm_box[0] is not None:
+                    comm_box[0].free()
+                comm_box[0] = False
+                log(f"[spgemm] C-ABI exchange unavailable on at least one rank ({err}); falling back to torch.distributed all_to_all")
+        if use_cabi and comm_box[0]:
             comm = comm_box[0]
             shard = DeviceCsr.from_torch(offs0[rank + 1] - offs0[rank], n, blk.row_ptr, blk.col_idx, blk.vals, True)
+        else:
+            use_cabi = False
 
         def one_step_cabi(sort_rows=False):
             B, received = comm.allgather_csr(shard, offs0)  # values still in flight: only the numeric phase waits
