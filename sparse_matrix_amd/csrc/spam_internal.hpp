@@ -156,8 +156,10 @@ int scan_u64_to_u64(const uint64_t* d_in, uint64_t n, uint64_t* d_out, void* d_t
 // *d_flag |= 1 if any partial sum wrapped (checked_add overflow)
 int narrow_row_ptr(const uint64_t* d_in, uint64_t n, uint32_t* d_out, hipStream_t s);
 
-// d_out = d_in sorted in descending order (hipCUB radix sort; spam_spmv_rg.hip)
+// d_out = d_in sorted in descending order (rocPRIM radix sort; spam_spmv_rg.hip)
 int sort_u32_desc(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t s);
+// d_out = d_in sorted in ascending order on the low `bits` bits (the keys must not use higher ones)
+int sort_u32_asc(const uint32_t* d_in, uint32_t* d_out, uint64_t n, int bits, hipStream_t s);
 
 // ---- SpMV (spam_spmv.hip) ------------------------------------------------------------------------
 void spmv_plan_free(SpmvPlan* p);

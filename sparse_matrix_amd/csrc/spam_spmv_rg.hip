@@ -25,7 +25,10 @@
 //
 // Sums of f32 / f64 values are accumulated by LDS atomics in an order that varies from run to run: results are
 // reproducible to rounding, not bit for bit (i64 results are exact and bit-identical).
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>  // device radix sort of the analysis (AMD's native primitives; round 3
+#include <rocprim/types/double_buffer.hpp>      // went through hipCUB, the CUB-compatibility layer on top of them)
 
 #include <algorithm>
 #include <vector>
@@ -458,6 +461,44 @@ __global__ void rg_rank_kernel(const uint32_t* __restrict__ idx_of_rank, const u
   mask_rank[k] = mask[i];
   len_rank[k] = len[i];
 }
+// Ranks [k0, nl) in tiles of 64 (the ranks behind the hub rows are placed a whole tile at a time): per tile the number
+// of rows with a pair in each part and the entries of its rows — what the host's group walk needs of 64 masks and lengths.
+struct RgTileStat {
+  uint8_t cnt[SPMV_NPART];
+  uint8_t pad[3];
+  uint32_t ents;
+};
+static_assert(sizeof(RgTileStat) == 16, "RgTileStat layout");
+__global__ void rg_tile_stats_kernel(const uint16_t* __restrict__ mask_rank, const uint32_t* __restrict__ len_rank, uint32_t k0,
+                                     uint32_t nl, uint32_t nt, RgTileStat* __restrict__ st) {
+  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (t >= nt) return;
+  const uint32_t k = k0 + t * 64u + lane;
+  const uint32_t m = k < nl ? mask_rank[k] : 0u;
+  uint32_t e = k < nl ? len_rank[k] : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+  uint32_t mine = 0;
+#pragma unroll
+  for (int p = 0; p < SPMV_NPART; ++p) {
+    const uint32_t c = (uint32_t)__popcll(__ballot((m >> p) & 1u));
+    if ((int)lane == p) mine = c;
+  }
+  if (lane < (uint32_t)SPMV_NPART) st[t].cnt[lane] = (uint8_t)mine;
+  if (lane == 0) st[t].ents = e;
+}
+// ... and their per-slot arrays: rank k0 + i sits in slot slot0 + i, in the group of its tile, with one accumulator per pair
+__global__ void rg_slot_fill_kernel(const RgTile* __restrict__ tiles, const uint16_t* __restrict__ mask_rank, uint32_t k0,
+                                    uint32_t slot0, uint32_t nl, uint32_t* __restrict__ rk_grp, uint32_t* __restrict__ rk_sub,
+                                    uint16_t* __restrict__ mask_slot, uint32_t* __restrict__ slot_of_rank) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k0 + i >= nl) return;
+  const uint32_t sl = slot0 + i;
+  rk_grp[sl] = tiles[sl >> 6].grp;
+  rk_sub[sl] = 1u << 16;
+  mask_slot[sl] = mask_rank[k0 + i];
+  slot_of_rank[k0 + i] = sl;
+}
 // rank -> slot: the row of every slot and the slot of every sliced row
 __global__ void rg_slot_kernel(const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ idx_of_rank,
                                const uint32_t* __restrict__ slot_of_rank, uint32_t nl, uint32_t* __restrict__ slot_rows,
@@ -747,10 +788,21 @@ struct RgGroup {
 int sort_u32_desc(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t s) {
   if (n == 0) return SPAM_OK;
   size_t tb = 0;
-  SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, tb, d_in, d_out, (int64_t)n, 0, 32, s));
+  SPAM_HIP_TRY(rocprim::radix_sort_keys_desc(nullptr, tb, d_in, d_out, (size_t)n, 0u, 32u, s));
   DevBuf tmp;
   SPAM_TRY(tmp.alloc(tb));
-  SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortKeysDescending(tmp.p, tb, d_in, d_out, (int64_t)n, 0, 32, s));
+  SPAM_HIP_TRY(rocprim::radix_sort_keys_desc(tmp.p, tb, d_in, d_out, (size_t)n, 0u, 32u, s));
+  SPAM_HIP_TRY(hipStreamSynchronize(s));  // tmp goes back to the pool
+  return SPAM_OK;
+}
+
+int sort_u32_asc(const uint32_t* d_in, uint32_t* d_out, uint64_t n, int bits, hipStream_t s) {
+  if (n == 0) return SPAM_OK;
+  size_t tb = 0;
+  SPAM_HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, d_in, d_out, (size_t)n, 0u, (unsigned)bits, s));
+  DevBuf tmp;
+  SPAM_TRY(tmp.alloc(tb));
+  SPAM_HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, d_in, d_out, (size_t)n, 0u, (unsigned)bits, s));
   SPAM_HIP_TRY(hipStreamSynchronize(s));  // tmp goes back to the pool
   return SPAM_OK;
 }
@@ -791,20 +843,23 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
                                    len.as<uint32_t>(), key_in.as<uint32_t>(), idx_in.as<uint32_t>(), mask.as<uint16_t>());
   SPAM_CHECK_LAUNCH();
   size_t tb = 0;
-  SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key_in.as<uint32_t>(), key_out.as<uint32_t>(), idx_in.as<uint32_t>(),
-                                                  idx_out.as<uint32_t>(), (int64_t)nl, 0, 32, s));
+  SPAM_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, key_in.as<uint32_t>(), key_out.as<uint32_t>(), idx_in.as<uint32_t>(),
+                                         idx_out.as<uint32_t>(), (size_t)nl, 0u, 32u, s));
   SPAM_TRY(tmp.alloc(tb));
-  SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key_in.as<uint32_t>(), key_out.as<uint32_t>(), idx_in.as<uint32_t>(),
-                                                  idx_out.as<uint32_t>(), (int64_t)nl, 0, 32, s));
+  SPAM_HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, key_in.as<uint32_t>(), key_out.as<uint32_t>(), idx_in.as<uint32_t>(),
+                                         idx_out.as<uint32_t>(), (size_t)nl, 0u, 32u, s));
   DevBuf mask_rank;
   SPAM_TRY(mask_rank.alloc((uint64_t)nl * 2 + 2));
   rg_rank_kernel<<<gl, 256, 0, s>>>(idx_out.as<uint32_t>(), mask.as<uint16_t>(), len.as<uint32_t>(), nl, mask_rank.as<uint16_t>(),
                                     key_in.as<uint32_t>() /* reused: lengths in rank order */);
   SPAM_CHECK_LAUNCH();
-  std::vector<uint32_t> h_len(nl);
-  std::vector<uint16_t> h_mask(nl);
-  SPAM_HIP_TRY(hipMemcpyAsync(h_len.data(), key_in.p, (uint64_t)nl * 4, hipMemcpyDeviceToHost, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(h_mask.data(), mask_rank.p, (uint64_t)nl * 2, hipMemcpyDeviceToHost, s));
+  // the host sees the lengths and masks of the leading ranks only (the hub rows, placed one by one below); the millions
+  // of ranks behind them reach it as per-tile statistics (round 3 downloaded 6 bytes per sliced row and walked them all)
+  uint32_t n_down = std::min<uint32_t>(nl, 1u << 16);
+  std::vector<uint32_t> h_len(n_down);
+  std::vector<uint16_t> h_mask(n_down);
+  SPAM_HIP_TRY(hipMemcpyAsync(h_len.data(), key_in.p, (uint64_t)n_down * 4, hipMemcpyDeviceToHost, s));
+  SPAM_HIP_TRY(hipMemcpyAsync(h_mask.data(), mask_rank.p, (uint64_t)n_down * 2, hipMemcpyDeviceToHost, s));
   DevBuf lofs, stmp;
   SPAM_TRY(lofs.alloc(((uint64_t)nl + 1) * 8));
   SPAM_TRY(stmp.alloc(scan_tmp_bytes(nl)));
@@ -825,11 +880,12 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
 
   // -- row groups and tiles (host): consecutive ranks; per part at most rmax accumulators, ecap entries in all.  Ranks
   //    are placed in SLOTS: a group starts on a multiple of 64 slots, so that tile t is slots [64 t, 64 t + 64) ----------
-  std::vector<uint32_t> h_slot(nl), h_sub_head;
+  std::vector<uint32_t> h_slot, h_sub_head;  // (h_slot and the by-slot vectors: the hub ranks' part only)
   std::vector<uint32_t> h_grp_s, h_rsub_s;   // by slot
   std::vector<uint16_t> h_mask_s;            // by slot (0 in a slot without row)
   std::vector<RgTile> h_tiles;
   std::vector<RgGroup> groups;
+  uint32_t khub = 0, slot0 = 0;  // hub ranks; first slot of the ranks behind them
   {
     RgGroup cur{};
     uint64_t ents = 0;
@@ -850,8 +906,19 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
       uint64_t n = (L * RG_MAX_SUB + ecap - 1) / ecap;
       return std::min<uint64_t>(std::max<uint64_t>(n, 1), std::min<uint64_t>(max_sub, std::max<uint64_t>(L, 1)));
     };
-    uint32_t khub = 0;  // ranks [0, khub) are placed one by one (lengths are non-increasing there)
-    while (khub < nl && nsub_of(h_len[khub]) > 1) ++khub;
+    // ranks [0, khub) are placed one by one (lengths are non-increasing there)
+    for (;;) {
+      while (khub < n_down && nsub_of(h_len[khub]) > 1) ++khub;
+      if (khub < n_down || n_down == nl) break;
+      // (more hub rows than downloaded so far: fetch twice as many)
+      const uint32_t more = (uint32_t)std::min<uint64_t>(nl, (uint64_t)n_down * 2);
+      h_len.resize(more), h_mask.resize(more);
+      SPAM_HIP_TRY(hipMemcpyAsync(h_len.data() + n_down, (const uint32_t*)key_in.p + n_down, (uint64_t)(more - n_down) * 4, hipMemcpyDeviceToHost, s));
+      SPAM_HIP_TRY(hipMemcpyAsync(h_mask.data() + n_down, (const uint16_t*)mask_rank.p + n_down, (uint64_t)(more - n_down) * 2, hipMemcpyDeviceToHost, s));
+      SPAM_HIP_TRY(hipStreamSynchronize(s));
+      n_down = more;
+    }
+    h_slot.resize(khub);
     for (uint32_t k = 0; k < khub; ++k) {
       const uint64_t L = h_len[k];
       // a row holding the fraction f of a block's entries draws 64 f lanes of every wave instruction: 8 x as many
@@ -881,24 +948,25 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
       ++slot;
     }
     if (khub < nl) {
-      // the rest, tile by tile, from the next tile boundary on
+      // the rest, tile by tile, from the next tile boundary on: the device condenses every 64 masks and lengths
       if (khub > 0) slot = (slot + 63u) & ~63u;
-      const uint64_t rest_tiles = ((uint64_t)(nl - khub) + 63) / 64;
-      const size_t need = (size_t)slot + (size_t)rest_tiles * 64;
-      h_grp_s.resize(need, 0u), h_rsub_s.resize(need, 0u), h_mask_s.resize(need, (uint16_t)0);
-      h_tiles.reserve(need / 64);
+      slot0 = slot;
+      const uint32_t rest_tiles = (uint32_t)(((uint64_t)(nl - khub) + 63) / 64);
+      DevBuf d_st;
+      SPAM_TRY(d_st.alloc((uint64_t)rest_tiles * sizeof(RgTileStat)));
+      rg_tile_stats_kernel<<<(rest_tiles + 3) / 4, 256, 0, s>>>(mask_rank.as<uint16_t>(), key_in.as<uint32_t>(), khub, nl, rest_tiles,
+                                                               d_st.as<RgTileStat>());
+      SPAM_CHECK_LAUNCH();
+      std::vector<RgTileStat> h_st(rest_tiles);
+      SPAM_HIP_TRY(hipMemcpyAsync(h_st.data(), d_st.p, (uint64_t)rest_tiles * sizeof(RgTileStat), hipMemcpyDeviceToHost, s));
+      SPAM_HIP_TRY(hipStreamSynchronize(s));
+      h_tiles.reserve(h_tiles.size() + rest_tiles);
       if (slot < (uint32_t)h_tiles.size() * 64u) h_tiles.pop_back();  // (the tile opened before the loop, still without rows)
-      for (uint32_t k0 = khub; k0 < nl; k0 += 64, slot += 64) {
-        const uint32_t n = std::min<uint32_t>(64, nl - k0);
-        uint32_t cnt[SPMV_NPART] = {0};
-        uint64_t tents = 0;
-        for (uint32_t j = 0; j < n; ++j) {
-          const uint32_t m = h_mask[k0 + j];
-          for (int p = 0; p < SPMV_NPART; ++p) cnt[p] += (m >> p) & 1u;
-          tents += h_len[k0 + j];
-        }
+      for (uint32_t ti = 0; ti < rest_tiles; ++ti, slot += 64) {
+        const RgTileStat& ts = h_st[ti];
+        const uint64_t tents = ts.ents;
         uint32_t worst = 0;
-        for (int p = 0; p < SPMV_NPART; ++p) worst = std::max(worst, cur.heads[p] + cnt[p]);
+        for (int p = 0; p < SPMV_NPART; ++p) worst = std::max(worst, cur.heads[p] + (uint32_t)ts.cnt[p]);
         const bool group_has_rows = ents > 0;
         if (group_has_rows && (worst + cur.nsubs > rmax || ents + tents > ecap)) {
           groups.push_back(cur);
@@ -910,14 +978,7 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
         t.grp = (uint32_t)groups.size();
         for (int p = 0; p < SPMV_NPART; ++p) t.base[p] = (uint16_t)cur.heads[p];
         h_tiles.push_back(t);
-        const uint32_t gid = (uint32_t)groups.size();
-        for (uint32_t j = 0; j < n; ++j) {
-          h_slot[k0 + j] = slot + j;
-          h_grp_s[slot + j] = gid;
-          h_rsub_s[slot + j] = 1u << 16;
-          h_mask_s[slot + j] = h_mask[k0 + j];
-        }
-        for (int p = 0; p < SPMV_NPART; ++p) cur.heads[p] += cnt[p];
+        for (int p = 0; p < SPMV_NPART; ++p) cur.heads[p] += ts.cnt[p];
         ents += tents;
       }
     }
@@ -993,11 +1054,25 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   SPAM_TRY(slot_rows.alloc(nslots * 4));
   SPAM_TRY(slot_of.alloc((uint64_t)nl * 4));
   SPAM_TRY(mask_slot.alloc(nslots * 2));
-  SPAM_HIP_TRY(hipMemcpyAsync(rk_grp.p, h_grp_s.data(), nslots * 4, hipMemcpyHostToDevice, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(rk_sub.p, h_rsub_s.data(), nslots * 4, hipMemcpyHostToDevice, s));
+  SPAM_HIP_TRY(hipMemsetAsync(rk_grp.p, 0, nslots * 4, s));
+  SPAM_HIP_TRY(hipMemsetAsync(rk_sub.p, 0, nslots * 4, s));
+  SPAM_HIP_TRY(hipMemsetAsync(mask_slot.p, 0, nslots * 2, s));  // 0 in a slot without row
   SPAM_HIP_TRY(hipMemcpyAsync(tiles.p, h_tiles.data(), (uint64_t)ntiles * sizeof(RgTile), hipMemcpyHostToDevice, s));
-  SPAM_HIP_TRY(hipMemcpyAsync(mask_slot.p, h_mask_s.data(), nslots * 2, hipMemcpyHostToDevice, s));  // (with the forced masks)
-  SPAM_HIP_TRY(hipMemcpyAsync(slot_of_rank.p, h_slot.data(), (uint64_t)nl * 4, hipMemcpyHostToDevice, s));
+  {  // the hub ranks' slots from the host (with the forced masks), everything behind them on the device
+    const uint64_t hub_slots = std::min<uint64_t>(h_grp_s.size(), nslots);
+    if (hub_slots) {
+      SPAM_HIP_TRY(hipMemcpyAsync(rk_grp.p, h_grp_s.data(), hub_slots * 4, hipMemcpyHostToDevice, s));
+      SPAM_HIP_TRY(hipMemcpyAsync(rk_sub.p, h_rsub_s.data(), hub_slots * 4, hipMemcpyHostToDevice, s));
+      SPAM_HIP_TRY(hipMemcpyAsync(mask_slot.p, h_mask_s.data(), hub_slots * 2, hipMemcpyHostToDevice, s));
+    }
+    if (khub) SPAM_HIP_TRY(hipMemcpyAsync(slot_of_rank.p, h_slot.data(), (uint64_t)khub * 4, hipMemcpyHostToDevice, s));
+    if (khub < nl) {
+      rg_slot_fill_kernel<<<(nl - khub + 255) / 256, 256, 0, s>>>(tiles.as<RgTile>(), mask_rank.as<uint16_t>(), khub, slot0, nl,
+                                                                rk_grp.as<uint32_t>(), rk_sub.as<uint32_t>(), mask_slot.as<uint16_t>(),
+                                                                slot_of_rank.as<uint32_t>());
+      SPAM_CHECK_LAUNCH();
+    }
+  }
   SPAM_HIP_TRY(hipMemcpyAsync(blk.p, h_blk.data(), ((uint64_t)nb + 1) * sizeof(RgBlk), hipMemcpyHostToDevice, s));
   SPAM_HIP_TRY(hipMemsetAsync(slot_rows.p, 0xFF, nslots * 4, s));  // RG_NONE in the slots without row
   rg_slot_kernel<<<gl, 256, 0, s>>>(long_rows, idx_out.as<uint32_t>(), slot_of_rank.as<uint32_t>(), nl, slot_rows.as<uint32_t>(),
@@ -1025,11 +1100,14 @@ int rg_build(const spam_csr* a, const uint8_t* slab, const uint32_t* code, const
   }
   const int end_bit = RG_KEY_BLK_SHIFT + bbits;
   tb = 0;
-  SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), src_in.as<uint32_t>(),
-                                                  src_out.as<uint32_t>(), (int64_t)n_all, RG_KEY_ACC_BITS, end_bit, s));
+  // (the two key / source buffers are the sort's ping and pong: no third copy of 162.7 M twelve-byte pairs in temporary storage)
+  rocprim::double_buffer<uint64_t> keys_db(keys_in.as<uint64_t>(), keys_out.as<uint64_t>());
+  rocprim::double_buffer<uint32_t> src_db(src_in.as<uint32_t>(), src_out.as<uint32_t>());
+  SPAM_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys_db, src_db, (size_t)n_all, (unsigned)RG_KEY_ACC_BITS, (unsigned)end_bit, s));
   SPAM_TRY(tmp.alloc(tb));
-  SPAM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys_in.as<uint64_t>(), keys_out.as<uint64_t>(), src_in.as<uint32_t>(),
-                                                  src_out.as<uint32_t>(), (int64_t)n_all, RG_KEY_ACC_BITS, end_bit, s));
+  SPAM_HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, keys_db, src_db, (size_t)n_all, (unsigned)RG_KEY_ACC_BITS, (unsigned)end_bit, s));
+  if (keys_db.current() != keys_out.as<uint64_t>()) std::swap(keys_in.p, keys_out.p);  // the sorted pairs are in keys_out / src_out
+  if (src_db.current() != src_out.as<uint32_t>()) std::swap(src_in.p, src_out.p);
   SPAM_HIP_TRY(hipStreamSynchronize(s));  // the host vectors above are read by the copies
   keys_in.reset(), src_in.reset(), tmp.reset(), hidx.reset();
 
