@@ -330,29 +330,17 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
   const uint32_t xcc = rg_xcc_id();
   const bool cold_first = ((blockIdx.x >> 3) & 3u) == 0u;
   int q = 0;
-#ifdef SPAM_RG_PRETICKET
-  __shared__ uint32_t s_pre;
-  bool have_pre = false;
-#endif
   for (;;) {
     uint32_t part;
     if (cold_first) part = q == 0 ? (uint32_t)SPMV_NSLAB : q == 1 ? RG_SHORT : q == 2 ? xcc : ((xcc + (uint32_t)(q - 2)) & 7u);
     else part = q == 0 ? xcc : q == 1 ? (uint32_t)SPMV_NSLAB : q == 2 ? RG_SHORT : ((xcc + (uint32_t)(q - 2)) & 7u);
-    // (drawing the next ticket while the block streams was measured 4 % slower: the atomic's return sits in front of
-    // wave 0's stream loads in the in-order vmcnt queue)
-    uint32_t g;
-#ifdef SPAM_RG_PRETICKET
-    if (have_pre) {  // (uniform) the ticket the last wavefront drew for this queue while the previous block streamed
-      g = __builtin_amdgcn_readfirstlane(s_pre);
-      have_pre = false;
-    } else
-#endif
-    {
-      if (threadIdx.x == 0) s_blk = atomicAdd(P.queue + (uint64_t)SPMV_HEAD_STRIDE * part, 1u);
-      __syncthreads();
-      g = __builtin_amdgcn_readfirstlane(s_blk);
-      __syncthreads();
-    }
+    // (drawing the next ticket while the block streams is slower — 4 % with thread 0 drawing it in round 3, 7 % with the
+    // last wavefront drawing it in round 4 (0.598 against 0.558 ms): a workgroup gets ~5 blocks per product, and committing
+    // to one of them a whole block early costs more balance at the end than the ticket's round trip costs in between)
+    if (threadIdx.x == 0) s_blk = atomicAdd(P.queue + (uint64_t)SPMV_HEAD_STRIDE * part, 1u);
+    __syncthreads();
+    const uint32_t g = __builtin_amdgcn_readfirstlane(s_blk);
+    __syncthreads();
     const bool is_short = part == RG_SHORT;
     if (g >= P.qcount[part]) {
       if (++q > SPMV_NSLAB + 1) break;
@@ -369,10 +357,6 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     if (P.times) t0 = wall_clock64();
     for (uint32_t i = threadIdx.x; i <= na; i += NT) acc[i] = AccT(0);  // [na] takes the padding entries
-#ifdef SPAM_RG_PRETICKET
-    uint32_t pre_t = 0;
-    if (threadIdx.x == NT - 64) pre_t = atomicAdd(P.queue + (uint64_t)SPMV_HEAD_STRIDE * part, 1u);  // in flight while the block streams
-#endif
     __syncthreads();
     if (P.times) t1 = wall_clock64();
     if (part >= (uint32_t)SPMV_NSLAB)
@@ -401,10 +385,6 @@ __global__ __launch_bounds__(NT) void spmv_rg_kernel(RgArgs<T> P) {
       T* out = P.cp + cp0;
       for (uint32_t i = threadIdx.x; i < nheads; i += NT) out[i] = (T)acc[i];
     }
-#ifdef SPAM_RG_PRETICKET
-    if (threadIdx.x == NT - 64) s_pre = pre_t;
-    have_pre = true;
-#endif
     __syncthreads();
     if (P.times && threadIdx.x == 0) {
       unsigned long long* t = P.times + 4ull * ((uint64_t)P.qbase[part] + g);
