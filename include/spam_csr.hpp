@@ -12,6 +12,7 @@
 #include <complex>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <utility>
 #include <stdexcept>
 #include <string>
@@ -100,6 +101,7 @@ class CsrMatrix {
     vals_ = std::move(o.vals_), indices_ = std::move(o.indices_), offsets_ = std::move(o.offsets_);
     dev_ = o.dev_;
     o.dev_ = nullptr;
+    part_[0] = std::move(o.part_[0]), part_[1] = std::move(o.part_[1]);
     return *this;
   }
   ~CsrMatrix() { release(); }
@@ -172,8 +174,8 @@ class CsrMatrix {
   CsrMatrix<T, B2> mul_hash(const CsrMatrix<T, B1>& rhs) const {
     if constexpr (kComplex) {
       // four real products with sorted rows (a sorted row is one of the orders B2 = false allows)
-      const auto ar = part(false), ai = part(true);
-      const auto br = rhs.part(false), bi = rhs.part(true);
+      const auto &ar = part(false), &ai = part(true);
+      const auto &br = rhs.part(false), &bi = rhs.part(true);
       auto rr = ar.template mul_hash<B1, true>(br), ii = ai.template mul_hash<B1, true>(bi);
       auto ri = ar.template mul_hash<B1, true>(bi), ir = ai.template mul_hash<B1, true>(br);
       if (rr.indices() != ii.indices() || rr.indices() != ri.indices() || rr.indices() != ir.indices() ||
@@ -205,8 +207,12 @@ class CsrMatrix {
 
   // the SpMV analysis on the uploaded copy (spam_spmv_prepare): worth it when the matrix is multiplied many times
   void spmv_prepare() const {
-    static_assert(!kComplex, "prepare the real and imaginary parts through spmv(): complex matrices hold no handle");
-    check(spam_spmv_prepare(const_cast<spam_csr*>(device()), nullptr));
+    if constexpr (kComplex) {  // a complex matrix multiplies through its two real parts: prepare both (they are cached)
+      part(false).spmv_prepare();
+      part(true).spmv_prepare();
+    } else {
+      check(spam_spmv_prepare(const_cast<spam_csr*>(device()), nullptr));
+    }
   }
 
   // y = A x (absent upstream; mul_hash with an n x 1 right-hand side)
@@ -216,7 +222,7 @@ class CsrMatrix {
       typedef typename detail::is_complex<T>::real R;
       std::vector<R> xr(x.size()), xi(x.size());
       for (size_t k = 0; k < x.size(); ++k) xr[k] = x[k].real(), xi[k] = x[k].imag();
-      const auto ar = part(false), ai = part(true);
+      const auto &ar = part(false), &ai = part(true);
       const auto rr = ar.spmv(xr), ii = ai.spmv(xi), ri = ar.spmv(xi), ir = ai.spmv(xr);
       std::vector<T> y(rows_);
       for (size_t k = 0; k < y.size(); ++k) y[k] = T(rr[k] - ii[k], ri[k] + ir[k]);
@@ -247,13 +253,20 @@ class CsrMatrix {
     return dev_;
   }
 
-  // complex values: the real (imag = false) or imaginary part as a real matrix over the same pattern
-  auto part(bool imag) const {
+  // complex values: the real (imag = false) or imaginary part as a real matrix over the same pattern.  Built on first
+  // use and kept, like dev_: its device handle and SpMV plan then survive from one product to the next (every complex
+  // mul_hash / spmv / + used to upload two to four real matrices again).
+  const auto& part(bool imag) const {
     static_assert(kComplex, "part() is for complex matrices");
     typedef typename detail::is_complex<T>::real R;
-    std::vector<R> v(vals_.size());
-    for (size_t k = 0; k < v.size(); ++k) v[k] = imag ? vals_[k].imag() : vals_[k].real();
-    return CsrMatrix<R, IS_SORTED>(rows_, cols_, std::move(v), indices_, offsets_);
+    typedef CsrMatrix<R, IS_SORTED> P;
+    std::shared_ptr<void>& slot = part_[imag ? 1 : 0];
+    if (!slot) {
+      std::vector<R> v(vals_.size());
+      for (size_t k = 0; k < v.size(); ++k) v[k] = imag ? vals_[k].imag() : vals_[k].real();
+      slot = std::make_shared<P>(rows_, cols_, std::move(v), indices_, offsets_);
+    }
+    return *static_cast<const P*>(slot.get());
   }
 
  private:
@@ -311,6 +324,7 @@ class CsrMatrix {
   std::vector<T> vals_;
   std::vector<uint64_t> indices_, offsets_;
   mutable spam_csr* dev_ = nullptr;
+  mutable std::shared_ptr<void> part_[2];  // complex matrices: the cached real / imaginary parts (CsrMatrix<R, IS_SORTED>)
 };
 
 }  // namespace spam
