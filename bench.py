@@ -542,23 +542,27 @@ def main():
             flops_row, _ = oracle.rows_to_threads(a_host[0], a_host[1], a_host[0], 1)
             ps = np.concatenate([[0], np.cumsum(flops_row.astype(np.float64))])
             mid = n // 2
-            r1 = max(mid + 1, min(int(np.searchsorted(ps, ps[mid] + min(2e8, ps[-1] - ps[mid]))), n))
+            sample_f = 2e9 if scale >= 20 else 2e8  # products in the CPU sample: ~10 s of work for 256 threads over three passes
+            r1 = max(mid + 1, min(int(np.searchsorted(ps, ps[mid] + min(sample_f, ps[-1] - ps[mid]))), n))
             s, e = int(a_host[0][mid]), int(a_host[0][r1])
             sub = (a_host[0][mid:r1 + 1] - a_host[0][mid], a_host[1][s:e], a_host[2][s:e])
             cores = oracle.hardware_threads()
-            t1 = time.perf_counter()
-            wo, wi, wv = oracle.mul_hash(sub, a_host, sort_rows=False, tnum=cores)
-            cpu_s = time.perf_counter() - t1
+            cpu_ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                wo, wi, wv = oracle.mul_hash(sub, a_host, sort_rows=False, tnum=cores)
+                cpu_ts.append(time.perf_counter() - t1)
+            cpu_s = float(np.median(cpu_ts))
             Fs = float(ps[r1] - ps[mid])
             sg["cpu_baseline"] = {"value": round(len(wi) / cpu_s / 1e6, 2), "unit": "Mnnz/s", "cores": cores, "kind": "port",
                                   "gflops": round(2 * Fs / cpu_s / 1e9, 3),
-                                  "sample": f"rows [{mid},{r1}) of A times full B: F={Fs:.3e}, nnz_out={len(wi)}, one pass, "
-                                            f"C++ restatement of mul_hash with tnum={cores}"}
+                                  "sample": f"rows [{mid},{r1}) of A times full B: F={Fs:.3e}, nnz_out={len(wi)}, median of 3 passes "
+                                            f"({', '.join(f'{t:.2f}' for t in cpu_ts)} s), C++ restatement of mul_hash with tnum={cores}"}
             # the same rows of the device product against the oracle (row_ptr exact, column sets, 1e-10; reference slot
             # order bit-exact) — also a -m gpu test (tests/test_spgemm_gpu.py::test_full_size_row_sum_property)
             try:
-                spgemm_rows_vs_oracle(oracle, B1, B1, C, a_host, a_host, mid, 2e8)
-                sg["parity_sample"] = (f"rows [{mid},{r1}): row_ptr exact, per-row column sets equal, values within 1e-10, reference slot "
+                pr1, _, _ = spgemm_rows_vs_oracle(oracle, B1, B1, C, a_host, a_host, mid, 2e8)  # (the parity sample: 2e8 products)
+                sg["parity_sample"] = (f"rows [{mid},{pr1}): row_ptr exact, per-row column sets equal, values within 1e-10, reference slot "
                                        f"order (sort_rows=2) col_idx bit-identical; status partial: {ORACLE_NOTE}")
             except AssertionError as ex:
                 sg["parity_sample"] = f"FAILED: {ex}"
