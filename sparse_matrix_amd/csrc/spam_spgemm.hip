@@ -1735,6 +1735,9 @@ __global__ __launch_bounds__(TPB, 4) void num_heavy_kernel(  // 4 waves per SIMD
       for (uint32_t i0 = wave * wpw; i0 < wend; i0 += 64) {
         const uint32_t i = i0 + lane;
         const RankWord wn = word_at(i + 64);  // the next step's word: its LDS round trip overlaps this step's stores
+        // (round 4: expanding DENSE steps — 256 / 512 / 1024 columns and more in the 64 words — one lane per column, with
+        // v_readlane pairs as lane masks, v_mbcnt ranks and 32 coalesced stores per step, measured 1.3-2.9 ms SLOWER than
+        // this per-word bit loop everywhere: 115.7 / 116.9 / 117.3 against 114.4 ms of numeric phase)
 #ifdef SPAM_ABLATE_DRAINCOLS  // (timing experiments only: results are wrong)
         if (false) {
 #else
