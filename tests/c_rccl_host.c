@@ -78,7 +78,7 @@ int main(int argc, char** argv) {
   /* partition (flop count sharded + all-gathered) + this rank's block of C = A A, sorted rows (B2 = true) */
   uint64_t blo = 0, bhi = 0;
   spam_spgemm_stats st;
-  CHECK(spam_spgemm_rank_step_rccl(comm, b_full, b_full, NULL, 4000, SPAM_ORDER_SORTED, &c_blk, &blo, &bhi, &st));
+  CHECK(spam_spgemm_rank_step_rccl(comm, b_full, b_full, NULL, SPAM_ROW_OVERHEAD_AUTO, SPAM_ORDER_SORTED, &c_blk, &blo, &bhi, &st));
 
   /* the gathered matrix equals the original, bit for bit */
   uint64_t* goff = malloc((n + 1) * 8);
