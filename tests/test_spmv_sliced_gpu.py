@@ -304,6 +304,11 @@ def test_row_groups_i64_exact_and_values_changed(spam, oracle, sliced_env):
     B.spmv_dev(tx.data_ptr(), ty.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(ty.cpu().numpy(), oracle.spmv((off, idx, val * 3), x))
+    tv.mul_(7)  # (a second change: the value-source map built by the first one is used)
+    B.values_changed()
+    B.spmv_dev(tx.data_ptr(), ty.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(ty.cpu().numpy(), oracle.spmv((off, idx, val * 21), x))
 
 
 @pytest.mark.parametrize("prepared", [True, False], ids=["prepared", "plain"])
@@ -483,6 +488,13 @@ def test_row_groups_packed_entry_words(spam, oracle, sliced_env, fmt, kind):
     B.spmv_dev(tx.data_ptr(), ty.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(ty.cpu().numpy(), oracle.spmv((off, idx, vi * 5), xi))
+    # the first change rebuilt the plan with its value-source map (spam_spmv_prepare does not build it); a second change
+    # takes the short way: every padded value position is re-gathered from its recorded source
+    tv.mul_(-3)
+    B.values_changed()
+    B.spmv_dev(tx.data_ptr(), ty.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(ty.cpu().numpy(), oracle.spmv((off, idx, vi * (-15)), xi))
     # the packed formats must actually shrink the stream where the deltas are small
     if kind == "dense_blocks":
         os.environ["SPAM_SPMV_RG_FMT"] = "0"
