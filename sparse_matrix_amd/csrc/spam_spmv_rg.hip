@@ -278,6 +278,10 @@ __device__ __forceinline__ void rg_stream_packed(const unsigned char* p0, const 
     }
   };
   uint32_t c = (uint32_t)wave;
+  // (round 4 measured a software pipeline here — the index words and chunk headers of a batch loaded one batch ahead, the
+  // values riding with the gathers, unconditional loads so that the compiler's vmcnt stays exact: 6 % SLOWER on both
+  // bench matrices (0.617 against 0.579 ms; 0.226 against 0.213).  The batch still waits one full HBM round trip for its
+  // values, the gathers it no longer waits for are L2 hits, and 133 live VGPRs against a budget of 128 spill.)
   for (; c + (uint32_t)(K - 1) * nw < nchunks; c += (uint32_t)K * nw) {
     uint32_t e[K][4], base[K], sl[K][4];
     T v[K][4], xv[K][4];

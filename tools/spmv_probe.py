@@ -4,7 +4,10 @@
 import os, sys, time, json
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from sparse_matrix_amd import DeviceCsr, _lib, synth
+from sparse_matrix_amd import _lib
+if os.environ.get("PROBE_LIB"):
+    _lib.LIB_PATH = os.environ["PROBE_LIB"]  # A/B two builds of the library
+from sparse_matrix_amd import DeviceCsr, synth
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "rmat"
