@@ -23,6 +23,7 @@ from __future__ import annotations
 import argparse
 import ctypes
 import hashlib
+import re
 import json
 import os
 import sys
@@ -56,12 +57,20 @@ def spgemm_alg_bytes(st, vsize):
     return (4 + vsize) * (st["nnz_a"] + st["nnz_b"] + st["nnz_c"]) + 4 * (st["rows"] + st["inner"] + st["rows"] + 3)
 
 
+def strip_comments(text: str) -> str:
+    """C / C++ source without comments and whitespace: the stamp below identifies the kernel CODE, so that a commit which
+    only rewords a comment does not orphan a measurement (string literals of the kernel sources hold no comment markers)."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
 def kernel_source_hash(*names) -> str:
-    """Stamp that ties a PMC file under profiles/ to the kernel sources it was measured on."""
+    """Stamp that ties a PMC file under profiles/ to the kernel code it was measured on."""
     h = hashlib.sha256()
     for n in names:
-        with open(os.path.join(ROOT, "sparse_matrix_amd", "csrc", n), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "sparse_matrix_amd", "csrc", n), "r") as f:
+            h.update(strip_comments(f.read()).encode())
     return h.hexdigest()[:16]
 
 

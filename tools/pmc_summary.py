@@ -15,9 +15,14 @@ out = sys.argv[1]
 
 
 def src_hash(*names):
+    """the same stamp as bench.py's kernel_source_hash: the kernel code without comments and whitespace"""
+    import re
     h = hashlib.sha256()
     for n in names:
-        h.update(open(os.path.join(ROOT, "sparse_matrix_amd", "csrc", n), "rb").read())
+        text = open(os.path.join(ROOT, "sparse_matrix_amd", "csrc", n), "r").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", "", text).encode())
     return h.hexdigest()[:16]
 
 
